@@ -1,0 +1,267 @@
+/*
+ * oracle/axt_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C CPU restatement of the numeric kernels on AxTrack's detect+associate hot path.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library; the product (axtrack_amd/) never does and has no CPU fallback.
+ *
+ * Each function cites the reference lines (relative to /root/reference) it restates.
+ * Pinning: checked against the .npz fixtures under tests/golden/, which were produced by running the
+ * reference's own Python (tests/golden/make_golden.py). The two third-party pieces that
+ * are absent from the reference tree -- pyastar2d (grid A*) and libmot/ortools (min-cost
+ * flow) -- are restated from their published algorithms; their parity is UNPINNED
+ * (see DESIGN.md), the conventions chosen are documented at orc_astar_len / orc_mcf_ssp.
+ *
+ * Build: make -C oracle   (gcc -O2 -fopenmp -shared -fPIC)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------
+ * CNNBlock.forward: Conv2d(3x3, pad 1, bias) -> BatchNorm2d(eval, eps 1e-5) -> LeakyReLU(0.1)
+ * model.py:5-18 (block), model.py:85-103 (padding=(1,1), kernel 3, stride from ARCHITECTURE).
+ * NCHW f32. Accumulation order: cin, ky, kx (textbook direct convolution) in f32, the
+ * reference's own order (oneDNN) is unspecified, so CNN parity is by tolerance.
+ * BN is applied UNFOLDED, as the reference does: (y - mean) / sqrt(var + eps) * gamma + beta.
+ * ------------------------------------------------------------------------------------ */
+void orc_conv3x3_bn_lrelu(const float *x, int B, int Cin, int H, int W,
+                          const float *w, const float *bias,
+                          const float *gamma, const float *beta, const float *mean, const float *var,
+                          int Cout, int stride, float slope, float *out)
+{
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int co = 0; co < Cout; ++co) {
+            float *o = out + ((size_t)b * Cout + co) * Ho * Wo;
+            for (int i = 0; i < Ho * Wo; ++i) o[i] = bias[co];
+            for (int ci = 0; ci < Cin; ++ci) {
+                const float *xi = x + ((size_t)b * Cin + ci) * H * W;
+                for (int ky = 0; ky < 3; ++ky)
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float wv = w[(((size_t)co * Cin + ci) * 3 + ky) * 3 + kx];
+                        for (int oy = 0; oy < Ho; ++oy) {
+                            const int iy = oy * stride + ky - 1;
+                            if (iy < 0 || iy >= H) continue;
+                            int ox0 = 0, ox1 = Wo;
+                            while (ox0 < Wo && ox0 * stride + kx - 1 < 0) ++ox0;
+                            while (ox1 > ox0 && (ox1 - 1) * stride + kx - 1 >= W) --ox1;
+                            const float *xr = xi + (size_t)iy * W + kx - 1;
+                            float *orow = o + (size_t)oy * Wo;
+                            for (int ox = ox0; ox < ox1; ++ox) orow[ox] += wv * xr[ox * stride];
+                        }
+                    }
+            }
+            const float inv = 1.0f / sqrtf(var[co] + 1e-5f);
+            for (int i = 0; i < Ho * Wo; ++i) {
+                float v = (o[i] - mean[co]) * inv * gamma[co] + beta[co];
+                o[i] = v > 0.f ? v : v * slope;
+            }
+        }
+}
+
+/* nn.MaxPool2d(2,2): model.py:100-101 */
+void orc_maxpool2(const float *x, int BC, int H, int W, float *out)
+{
+    const int Ho = H / 2, Wo = W / 2;
+#pragma omp parallel for schedule(static)
+    for (int c = 0; c < BC; ++c)
+        for (int y = 0; y < Ho; ++y)
+            for (int xx = 0; xx < Wo; ++xx) {
+                const float *p = x + ((size_t)c * H + 2 * y) * W + 2 * xx;
+                float m = p[0];
+                if (p[1] > m) m = p[1];
+                if (p[W] > m) m = p[W];
+                if (p[W + 1] > m) m = p[W + 1];
+                out[((size_t)c * Ho + y) * Wo + xx] = m;
+            }
+}
+
+/* nn.Linear (+ optional nn.Sigmoid): model.py:105-117. w is [out, in] row-major. */
+void orc_linear(const float *x, int B, int In, const float *w, const float *bias, int Out,
+                int sigmoid, float *out)
+{
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int o = 0; o < Out; ++o) {
+            const float *xr = x + (size_t)b * In, *wr = w + (size_t)o * In;
+            /* 8 partial sums keep the f32 error near what a blocked BLAS gives */
+            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int i = 0;
+            for (; i + 8 <= In; i += 8)
+                for (int k = 0; k < 8; ++k) acc[k] += xr[i + k] * wr[i + k];
+            float s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+            for (; i < In; ++i) s += xr[i] * wr[i];
+            s += bias[o];
+            out[(size_t)b * Out + o] = sigmoid ? 1.0f / (1.0f + expf(-s)) : s;
+        }
+}
+
+/* ------------------------------------------------------------------------------------
+ * pyastar2d.astar_path(weights, source, target, max_path_length) as called at
+ * utils.py:379, consumed at AxonDetections.py:624,736 -- only the LENGTH of the path
+ * (number of cells including both end points) is used downstream.
+ *
+ * pyastar2d (fork LoaloaF/pyastar2d, pin pyastar2d==1.0.2, axtr.yml:140) is NOT in the
+ * reference tree: PARITY UNPINNED. Convention restated from the published upstream
+ * algorithm: A* on the pixel grid, cost of a move = weight of the cell moved INTO,
+ * 4-connected by default (conn8 != 0: 8-connected, diagonal moves cost the same), optimal
+ * because the L1 / Chebyshev heuristic times min(weights) >= 1 is admissible. Returns the
+ * number of cells on a minimum-cost path, or 0 ("None") when that path has more than
+ * max_len cells. For weights in {1, 65536} (AxonDetections.py:598) every minimum-cost
+ * path has the same cell count, so the result does not depend on tie-breaking; we
+ * therefore run Dijkstra on (cost, cells) which is exact and simple.
+ * ------------------------------------------------------------------------------------ */
+typedef struct { double cost; int32_t cell; } heap_item;
+
+static void heap_push(heap_item *h, int *n, heap_item it)
+{
+    int i = (*n)++;
+    while (i > 0) {
+        int p = (i - 1) / 2;
+        if (h[p].cost <= it.cost) break;
+        h[i] = h[p];
+        i = p;
+    }
+    h[i] = it;
+}
+
+static heap_item heap_pop(heap_item *h, int *n)
+{
+    heap_item top = h[0], last = h[--(*n)];
+    int i = 0;
+    for (;;) {
+        int c = 2 * i + 1;
+        if (c >= *n) break;
+        if (c + 1 < *n && h[c + 1].cost < h[c].cost) ++c;
+        if (h[c].cost >= last.cost) break;
+        h[i] = h[c];
+        i = c;
+    }
+    h[i] = last;
+    return top;
+}
+
+int orc_astar_len(const float *weights, int H, int W, int sy, int sx, int ty, int tx,
+                  int max_len, int conn8)
+{
+    if (sy < 0 || sy >= H || sx < 0 || sx >= W || ty < 0 || ty >= H || tx < 0 || tx >= W) return 0;
+    /* search window: a minimum-cost path of <= max_len cells stays inside it */
+    const int y0 = (sy - max_len < 0) ? 0 : sy - max_len, y1 = (sy + max_len >= H) ? H - 1 : sy + max_len;
+    const int x0 = (sx - max_len < 0) ? 0 : sx - max_len, x1 = (sx + max_len >= W) ? W - 1 : sx + max_len;
+    const int wh = y1 - y0 + 1, ww = x1 - x0 + 1;
+    double *cost = (double *)malloc(sizeof(double) * wh * ww);
+    int32_t *cells = (int32_t *)malloc(sizeof(int32_t) * wh * ww);
+    heap_item *heap = (heap_item *)malloc(sizeof(heap_item) * (size_t)wh * ww * 4 + 16);
+    for (int i = 0; i < wh * ww; ++i) { cost[i] = INFINITY; cells[i] = 0; }
+    int hn = 0, result = 0;
+    const int s = (sy - y0) * ww + (sx - x0), t = (ty - y0) * ww + (tx - x0);
+    if (ty < y0 || ty > y1 || tx < x0 || tx > x1) goto done;
+    cost[s] = 0; cells[s] = 1;
+    heap_push(heap, &hn, (heap_item){0.0, s});
+    static const int dy8[8] = {-1, 1, 0, 0, -1, -1, 1, 1}, dx8[8] = {0, 0, -1, 1, -1, 1, -1, 1};
+    const int nn = conn8 ? 8 : 4;
+    while (hn > 0) {
+        heap_item it = heap_pop(heap, &hn);
+        if (it.cost > cost[it.cell]) continue;
+        if (it.cell == t) break;
+        const int cy = it.cell / ww, cx = it.cell % ww;
+        for (int k = 0; k < nn; ++k) {
+            const int ny = cy + dy8[k], nx = cx + dx8[k];
+            if (ny < 0 || ny >= wh || nx < 0 || nx >= ww) continue;
+            const int nc = ny * ww + nx;
+            const double c = it.cost + (double)weights[(size_t)(ny + y0) * W + (nx + x0)];
+            if (c < cost[nc]) {
+                cost[nc] = c;
+                cells[nc] = cells[it.cell] + 1;
+                heap_push(heap, &hn, (heap_item){c, nc});
+            }
+        }
+    }
+    if (cells[t] > 0 && cells[t] <= max_len) result = cells[t];
+done:
+    free(cost); free(cells); free(heap);
+    return result;
+}
+
+/* D[i][j] for all pairs, with the euclidean gate of AxonDetections.py:617-629 and the
+ * None -> max_dist conversion of :736. src = detections at t_bef (rows), dst = at t. */
+void orc_path_matrix(const float *weights, int H, int W,
+                     const int64_t *src_x, const int64_t *src_y, int ns,
+                     const int64_t *dst_x, const int64_t *dst_y, int nd,
+                     int max_dist, int conn8, int32_t *D)
+{
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int p = 0; p < ns * nd; ++p) {
+        const int i = p / nd, j = p % nd;
+        const double dy = (double)(src_y[i] - dst_y[j]), dx = (double)(src_x[i] - dst_x[j]);
+        int len = 0;
+        if (sqrt(dy * dy + dx * dx) < (double)max_dist)
+            len = orc_astar_len(weights, H, W, (int)src_y[i], (int)src_x[i], (int)dst_y[j], (int)dst_x[j],
+                                max_dist, conn8);
+        D[p] = len ? len : max_dist;
+    }
+}
+
+/* ------------------------------------------------------------------------------------
+ * libmot.data_association.MinCostFlowTracker.compute_trajectories(), call site
+ * AxonDetections.py:663-690. libmot (fork LoaloaF/libmot, libmot==0.0.2, ortools 9.0) is
+ * NOT in the reference tree: PARITY UNPINNED. Restated from the published formulation
+ * (Zhang, Li, Nevatia, CVPR 2008, as implemented by libmot): unit-capacity network with
+ * integer arc costs; the number of unit flows F in [min_flow, max_flow] minimising the
+ * total cost is searched (libmot: Fibonacci search over F, each probe a min-cost-flow
+ * solve; the cost is convex in F, so successive shortest paths reaches the same optimum).
+ *
+ * This oracle is the slow, obviously-correct form: Bellman-Ford shortest augmenting paths.
+ * Graph is given as arc lists; node 0 = source, node 1 = sink.
+ *   returns number of unit flows pushed (0 if < min_flow is infeasible -> *feasible = 0)
+ *   flow_out[a] = 1 if arc a carries flow.
+ * Stop rule: push while (F < min_flow) or (F < max_flow and next path cost < 0).
+ * ------------------------------------------------------------------------------------ */
+int orc_mcf_ssp(int n_nodes, int n_arcs, const int32_t *tail, const int32_t *head, const int64_t *cost,
+                int min_flow, int max_flow, uint8_t *flow_out, int64_t *total_cost, int *feasible)
+{
+    int64_t *dist = (int64_t *)malloc(sizeof(int64_t) * n_nodes);
+    int32_t *pred = (int32_t *)malloc(sizeof(int32_t) * n_nodes);
+    memset(flow_out, 0, n_arcs);
+    const int64_t INF = INT64_MAX / 4;
+    int F = 0;
+    int64_t tot = 0;
+    *feasible = 1;
+    while (F < max_flow) {
+        for (int v = 0; v < n_nodes; ++v) { dist[v] = INF; pred[v] = -1; }
+        dist[0] = 0;
+        for (int it = 0; it < n_nodes; ++it) {
+            int changed = 0;
+            for (int a = 0; a < n_arcs; ++a) {
+                if (!flow_out[a]) {              /* forward residual arc */
+                    if (dist[tail[a]] < INF && dist[tail[a]] + cost[a] < dist[head[a]]) {
+                        dist[head[a]] = dist[tail[a]] + cost[a]; pred[head[a]] = a; changed = 1;
+                    }
+                } else {                          /* backward residual arc */
+                    if (dist[head[a]] < INF && dist[head[a]] - cost[a] < dist[tail[a]]) {
+                        dist[tail[a]] = dist[head[a]] - cost[a]; pred[tail[a]] = a; changed = 1;
+                    }
+                }
+            }
+            if (!changed) break;
+        }
+        if (dist[1] >= INF) break;
+        if (F >= min_flow && dist[1] >= 0) break;
+        /* augment */
+        int v = 1;
+        while (v != 0) {
+            const int a = pred[v];
+            if (!flow_out[a] && head[a] == v) { flow_out[a] = 1; v = tail[a]; }
+            else { flow_out[a] = 0; v = head[a]; }
+        }
+        tot += dist[1];
+        ++F;
+    }
+    if (F < min_flow) *feasible = 0;
+    *total_cost = tot;
+    free(dist); free(pred);
+    return F;
+}

@@ -1,0 +1,287 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING the reference's own Python.
+
+Run only in the build container (needs /root/reference, read-only):
+
+    python tests/golden/make_golden.py
+
+Inputs are produced by axtrack_amd.synth (seeded, no reference code); expected outputs are
+whatever the reference computes for them. Nothing of the reference's source is stored --
+only input descriptions (seeds/sizes or small arrays) and output arrays.
+
+Fixture files (all .npz, each < 1 MB):
+  cnn_512.npz        YOLO_AXTrack.detect_axons on 5 frames of a 512x512 timelapse   (model.py:119-125)
+  detect_1024.npz    AxonDetections.detect_dataset on 1024x1024 (4 tiles)            (AxonDetections.py:87-139)
+  detect_ragged.npz  same on 700x600 (zero-padded edge tiles) with one all-empty tile (Timelapse.py:492-566)
+  detect_crafted.npz decode/stitch/NMS on crafted YOLO tensors (dense, ties at d=23) (AxonDetections.py:178-278)
+  assoc_parts.npz    det2libmot, conf capping, observation_model, transition_model,
+                     _get_astar_path_distances, libmot_det2det, _agg_all_IDed_dets   (AxonDetections.py:653-842,
+                                                                                      mincostflow_models.py:6-119)
+"""
+import copy
+import os
+import sys
+
+import numpy as np
+import pandas as pd
+import torch
+from scipy import sparse
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, '..', '..'))
+
+from _ref_import import import_reference  # noqa: E402
+from axtrack_amd import synth             # noqa: E402
+
+ref = import_reference()
+from reference.axtrack.exp_parameters import load_parameters          # noqa: E402
+from reference.axtrack.machinelearning.model import YOLO_AXTrack      # noqa: E402
+from reference.axtrack.Timelapse import Timelapse                     # noqa: E402
+from reference.axtrack.AxonDetections import AxonDetections           # noqa: E402
+from reference.axtrack import mincostflow_models as ref_mcf           # noqa: E402
+
+torch.set_num_threads(8)
+P = load_parameters(exp_name=None, run=None, from_directory='/root/reference/deployed_model')
+P['DEVICE'] = 'cpu'
+
+
+def ref_model(seed=42):
+    model = YOLO_AXTrack(5, copy.deepcopy(P['ARCHITECTURE']), P['ACTIVATION_FUNCTION'],
+                         P['TILESIZE'], P['SY'], P['SX'])
+    sd = synth.synth_state_dict(seed)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    return model
+
+
+class FixedOutputModel:
+    """Stands in for the detector where a fixture feeds crafted YOLO tensors downstream."""
+    def __init__(self, outputs):
+        self.outputs, self.i = outputs, 0
+
+    def detect_axons(self, X):
+        y = self.outputs[self.i]
+        self.i += 1
+        return torch.from_numpy(y.copy())
+
+
+def ref_timelapse(frames, mask2d=None, name='synth'):
+    """A reference Timelapse holding `frames` (f32 [T_all,H,W], already preprocessed).
+
+    __init__ is bypassed (it reads a .tif through tifffile/skimage, which are absent); the
+    attributes it would set are filled in the way Timelapse.py:37-109,426-433 does. All
+    methods used afterwards (construct_tiles, get_frametiles_stack, stitch_tiles, ...) are
+    the reference's own.
+    """
+    T_all, H, W = frames.shape
+    tl = object.__new__(Timelapse)
+    torch.utils.data.Dataset.__init__(tl)
+    tl.name = name
+    tl.transform_configs = {}
+    tl.use_motion_filtered = P['USE_MOTION_DATA']
+    tl.temporal_context = P['TEMPORAL_CONTEXT']
+    tl.pad = None
+    tl.sizet, tl.sizey, tl.sizex = T_all, H, W
+    tl.size_chnls, tl.size_colchnls = tl._get_channelsizes()
+    tl.Sy, tl.Sx, tl.tilesize = P['SY'], P['SX'], P['TILESIZE']
+    tl.xtiles = np.ceil((W / tl.tilesize)).astype(int).item()
+    tl.ytiles = np.ceil((H / tl.tilesize)).astype(int).item()
+    tl.timepoints = np.arange(tl.temporal_context, T_all - tl.temporal_context)
+    if mask2d is None:
+        mask2d = np.ones((H, W), bool)
+    tl.imseq = [sparse.coo_matrix(f) for f in frames]
+    tl.mask = [sparse.coo_matrix(mask2d) for _ in range(T_all)]
+    zero = sparse.coo_matrix(np.zeros((H, W)))
+    tl.p_motion_seq = tl.n_motion_seq = [zero for _ in range(T_all)]
+    tl.target = tl._load_bboxes(None)
+    (tl.timepoints_indices, tl.sizet, tl.target, tl.imseq, tl.mask,
+     tl.p_motion_seq, tl.n_motion_seq) = tl._slice_timepoints()
+    tl.X = tl._construct_X_tensor()
+    del tl.imseq
+    return tl
+
+
+def dets_to_arrays(dets):
+    """list of per-frame DataFrames -> (counts, conf f32, x i64, y i64) flat arrays."""
+    counts = np.array([len(d) for d in dets], np.int64)
+    conf = np.concatenate([d.conf.to_numpy(dtype=np.float32, na_value=np.nan) for d in dets] or [np.zeros(0, np.float32)])
+    x = np.concatenate([d.anchor_x.to_numpy(dtype=np.int64) for d in dets] or [np.zeros(0, np.int64)])
+    y = np.concatenate([d.anchor_y.to_numpy(dtype=np.int64) for d in dets] or [np.zeros(0, np.int64)])
+    return counts, conf, x, y
+
+
+def run_detect(frames, model, name, capture_yolo=True):
+    tl = ref_timelapse(frames, name=name)
+    yolo = []
+    if capture_yolo:
+        inner = model
+
+        class Tap:
+            def detect_axons(self, X):
+                y = inner.detect_axons(X)
+                yolo.append(y.numpy().copy())
+                return y
+        model = Tap()
+    ad = AxonDetections(model, tl, P, None)
+    ad.detect_dataset(cache=None)
+    return tl, ad, yolo
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print(f'wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB')
+
+
+# --------------------------------------------------------------------------- cnn_512
+def gen_cnn_512():
+    frames = synth.synth_frames(9, 512, 512, seed=0)
+    model = ref_model(42)
+    X = torch.stack([torch.from_numpy(frames[t:t + 5]) for t in range(5)])
+    y = model.detect_axons(X).numpy()
+    # also the conv-stack output statistics, to localise a mismatch
+    model.eval()
+    with torch.no_grad():
+        h = model.ConvNet(X[:1])
+    save('cnn_512.npz', frames_seed=0, T_all=9, H=512, W=512, weights_seed=42,
+         yolo=y, conv_out_sample=h[0, ::16, ::3, ::3].numpy())
+
+
+# --------------------------------------------------------------------------- detect_*
+def gen_detect(name, T_all, H, W, seed, zero_tile=None):
+    frames = synth.synth_frames(T_all, H, W, seed=seed)
+    if zero_tile is not None:
+        ty, tx = zero_tile
+        frames[:, ty * 512:(ty + 1) * 512, tx * 512:(tx + 1) * 512] = 0
+    tl, ad, yolo = run_detect(frames, ref_model(42), name)
+    counts, conf, x, y = dets_to_arrays(ad._detections)
+    # the per-tile tables before stitching (ascending conf), flattened: [frame, tile, conf, x, y]
+    rows = []
+    for t, tiles in enumerate(ad._pandas_tiled_dets):
+        for k, d in enumerate(tiles):
+            for c, ax, ay in zip(d.conf.to_numpy(dtype=np.float64), d.anchor_x.to_numpy(dtype=np.int64),
+                                 d.anchor_y.to_numpy(dtype=np.int64)):
+                rows.append((t, k, c, ax, ay))
+    kept = tl.tile_info[..., 0].any(-1).numpy()
+    save(name + '.npz', frames_seed=seed, T_all=T_all, H=H, W=W, weights_seed=42,
+         zero_tile=np.array(zero_tile if zero_tile is not None else [-1, -1]),
+         kept_tiles=kept, yolo=np.stack(yolo), counts=counts, conf=conf, x=x, y=y,
+         tiled=np.array(rows, np.float64))
+    return tl, ad
+
+
+# --------------------------------------------------------------------------- detect_crafted
+def gen_detect_crafted():
+    T_all, H, W = 8, 1024, 1024           # 4 frames, 4 tiles
+    frames = synth.synth_frames(T_all, H, W, seed=3)
+    n_frames = T_all - 4
+    rng_u = synth.uniform01(777, (n_frames, 4, 12, 12, 3))
+    yolo = np.empty((n_frames, 4, 12, 12, 3), np.float32)
+    yolo[..., 0] = (0.3 + 0.9 * rng_u[..., 0])                 # ~72 % pass the floor, some > 1
+    yolo[..., 1:] = (-0.3 + 1.6 * rng_u[..., 1:])              # anchors spill into neighbouring cells/tiles
+    # frame 1: exact confidence ties inside a tile and across tiles
+    yolo[1, :, :6, :, 0] = np.float32(0.8)
+    # frame 2: pairs at distance exactly 23 (dx=23, dy=0) and sqrt(528) (dx=22, dy=sqrt(44)~ no: use 20,11 -> 521; 23,0 -> 529)
+    yolo[2] = 0
+    cells = [((0, 0), 0.95, (10, 20)), ((0, 1), 0.90, (33, 20)),      # d^2 = 23^2 = 529 -> both survive
+             ((3, 3), 0.93, (150, 150)), ((3, 4), 0.70, (170, 161)),   # d^2 = 400+121 = 521 -> second dies
+             ((6, 6), 0.60, (300, 300)), ((7, 6), 0.99, (322, 306))]   # d^2 = 484+36 = 520 -> first dies
+    for (i, j), c, (px, py) in cells:
+        # choose in-cell coordinates that decode exactly to (px, py): v = p*12/512 - idx
+        yolo[2, 0, i, j] = (c, px * 12 / 512 - i, py * 12 / 512 - j)
+    # frame 3: values that land exactly on .5 before rounding (half-to-even) and exact threshold
+    yolo[3] = 0
+    yolo[3, 1, 2, 2] = (np.float32(0.55), 0.0 + 1 / 24 * 0, 0.5)       # conf == f32(0.55) -> kept
+    yolo[3, 1, 4, 4] = (np.nextafter(np.float32(0.55), np.float32(0)), 0.5, 0.5)   # just below -> dropped
+    yolo[3, 1, 5, 5] = (0.9, (214.5 * 12 / 512) - 5, (215.5 * 12 / 512) - 5)       # x.5 ties: 214.5->214, 215.5->216
+    yolo[3, 2, 0, 0] = (0.9, -0.3, -0.3)                                           # negative anchors, no clamp
+    yolo[3, 3, 11, 11] = (1.3, 1.2, 1.2)                                           # beyond the tile edge
+    tl = ref_timelapse(frames, name='crafted')
+    ad = AxonDetections(FixedOutputModel([yolo[t] for t in range(n_frames)]), tl, P, None)
+    ad.detect_dataset(cache=None)
+    counts, conf, x, y = dets_to_arrays(ad._detections)
+    save('detect_crafted.npz', T_all=T_all, H=H, W=W, frames_seed=3, yolo=yolo,
+         counts=counts, conf=conf, x=x, y=y)
+
+
+# --------------------------------------------------------------------------- assoc_parts
+def gen_assoc_parts(tl, ad):
+    out = {}
+    # a-7: libmot format of all detections (object ndarray in the reference)
+    dets = ad.get_frame_dets('all', None, libmot=True).reset_index().values
+    out['libmot_dtype_names'] = np.array([type(v).__name__ for v in dets[0]])
+    out['libmot'] = dets.astype(np.float64)
+    # a-8: conf capping, both methods, done exactly as AxonDetections.py:655-659
+    d_scale = dets.copy()
+    d_scale[:, -1] /= d_scale[:, -1].max()
+    out['conf_scale_to_max'] = d_scale[:, -1].astype(np.float64)
+    out['conf_scale_to_max_elem_type'] = np.array(type(d_scale[0, -1]).__name__)
+    d_ceil = dets.copy()
+    d_ceil[:, -1][d_ceil[:, -1] > 1] = 1
+    out['conf_ceil'] = d_ceil[:, -1].astype(np.float64)
+    # a-10: observation costs on the capped scores, per frame as the tracker is fed (:681-684)
+    obs = []
+    for i in range(len(ad)):
+        det = d_scale[(d_scale[:, 0] == i), :]
+        obs.append(ref_mcf.observation_model(scores=det[:, 6], max_conf_cost=P['MCF_MAX_CONF_COST']))
+    out['obs_cost'] = np.concatenate(obs)
+    # a-11: transition costs for every integer distance 1..500 and gaps 1, 2 (vis weight 0)
+    D = np.arange(1, 501, dtype=np.int64).reshape(1, -1)
+    for gap in (1, 2):
+        lbl = f'x_t:{5:0>3}-t:{5 - gap:0>3}'
+        c = ref_mcf.transition_model(miss_rate=P['MCF_MISS_RATE'], time_gap=gap, boxes=np.zeros((500, 4)),
+                                     predecessor_boxes=np.zeros((1, 4)), features=[0] * 500,
+                                     predecessor_features=[0], frame_idx=5, dataset_name='x',
+                                     astar_dists={lbl: D}, max_px_assoc_dist=500,
+                                     vis_sim_weight=P['MCF_VIS_SIM_WEIGHT'])
+        out[f'trans_cost_gap{gap}'] = c[0]
+    # a-9 (conversion half): paths -> lengths, None -> 500   (:717-752)
+    def path(n):
+        if n is None:
+            return None
+        return sparse.coo_matrix((np.ones(n), (np.arange(n), np.zeros(n, int))), (600, 600), bool)
+    paths = {'k_t:001-t:000': [[path(3), None, path(500)], [path(1), path(77), None]],
+             'k_t:002-t:001': [[path(9)], [None], [path(250)]]}
+    dd = ad._get_astar_path_distances(paths)
+    out['astar_len_0'] = np.asarray(dd['k_t:001-t:000'])
+    out['astar_len_1'] = np.asarray(dd['k_t:002-t:001'])
+    # a-13: trajectories -> IDed tables -> IDed_dets_all, including a frame without any IDed
+    # detection (the frame-label quirk, :833-839). Trajectories are synthetic: ID k follows
+    # detection k of every frame it visits.
+    nfr = len(ad)
+    traj = []
+    counts = [len(d) for d in ad._detections]
+    skip_frame = 1
+    for k in range(6):
+        tr = []
+        for f in range(nfr):
+            if f == skip_frame or k >= counts[f] or (k == 4 and f > 1):
+                continue
+            row = ad._detections[f].iloc[k]
+            tr.append([f, k, (int(row.anchor_x) - 35, int(row.anchor_y) - 35, 70, 70)])
+        traj.append(tr)
+    record = []
+    for i, t in enumerate(traj):
+        for j, box in enumerate(t):
+            record.append([box[0], i, box[2][0], box[2][1], box[2][2], box[2][3]])
+    track = np.array(record)
+    track = track[np.argsort(track[:, 0])]
+    cols = ['FrameId', 'Id', 'X', 'Y', 'Width', 'Height']
+    lib = pd.DataFrame(track, columns=cols).set_index(['FrameId', 'Id'])
+    ad._IDed_detections = ad.libmot_det2det(lib)
+    allp = ad._agg_all_IDed_dets()
+    out['traj'] = np.array([(i, b[0], b[1]) for i, t in enumerate(traj) for b in t], np.int64)
+    out['ided_all_values'] = allp.to_numpy(dtype=np.float64, na_value=np.nan)
+    out['ided_all_index'] = np.array(list(allp.index))
+    out['ided_all_cols_frame'] = np.array([c[0] for c in allp.columns], np.float64)
+    out['ided_all_cols_info'] = np.array([c[1] for c in allp.columns])
+    out['ided_frame_counts'] = np.array([len(d) for d in ad._IDed_detections], np.int64)
+    save('assoc_parts.npz', **out)
+
+
+if __name__ == '__main__':
+    gen_cnn_512()
+    tl, ad = gen_detect('detect_1024', 7, 1024, 1024, seed=1)
+    gen_assoc_parts(tl, ad)
+    gen_detect('detect_ragged', 6, 700, 1100, seed=2, zero_tile=(1, 2))
+    gen_detect_crafted()
