@@ -1,0 +1,268 @@
+// Association costs on gfx950: observation costs, path-length matrices and the admissible-arc list.
+//
+// Replaces, from the reference:
+//   conf capping + observation_model      AxonDetections.py:655-659, mincostflow_models.py:6-27
+//   _compute_detections_astar_paths / _get_astar_path_distances   AxonDetections.py:526-629,717-752
+//   the tracker's edge admission (transition_model + cost_threshold)   mincostflow_models.py:67-119
+//
+// Path length convention (pyastar2d is absent from the reference tree): number of cells of a
+// minimum-cost 4-connected (or 8-connected) path, both end points included; `max_dist` when the euclidean
+// distance is >= max_dist, an end point lies outside the grid or the path needs more than max_dist cells.
+// On an all-ones mask that is |dx|+|dy|+1 (max(|dx|,|dy|)+1) in closed form; masked grids run a
+// breadth-first search per source (path_bfs.hip).
+#include "axt_common.h"
+
+int axt_path_cost_masked(const int32_t *d_xa, const int32_t *d_ya, int na, const int32_t *d_xb, const int32_t *d_yb,
+                         int nb, const uint8_t *d_mask, int H, int W, int max_dist, int conn8, int32_t *d_D,
+                         hipStream_t st);
+
+namespace {
+
+__device__ __forceinline__ int path_len_open(int xa, int ya, int xb, int yb, int H, int W, int max_dist, int conn8)
+{
+    const int dx = abs(xa - xb), dy = abs(ya - yb);
+    // euclidean gate, AxonDetections.py:620-628: sqrt(dy^2+dx^2) < 500  <=>  dx^2+dy^2 < 500^2 (integers)
+    const long d2 = (long)dx * dx + (long)dy * dy;
+    const int len = (conn8 ? max(dx, dy) : dx + dy) + 1;
+    const bool inb = xa >= 0 && xa < W && ya >= 0 && ya < H && xb >= 0 && xb < W && yb >= 0 && yb < H;
+    return (d2 < (long)max_dist * max_dist && len <= max_dist && inb) ? len : max_dist;
+}
+
+__global__ void path_cost_open_kernel(const int *__restrict__ xa, const int *__restrict__ ya, int na,
+                                      const int *__restrict__ xb, const int *__restrict__ yb, int nb, int H, int W,
+                                      int max_dist, int conn8, int *__restrict__ D)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)na * nb) return;
+    const int i = idx / nb, j = idx - (long)i * nb;
+    D[idx] = path_len_open(xa[i], ya[i], xb[j], yb[j], H, W, max_dist, conn8);
+}
+
+// ---- observation costs -------------------------------------------------------------------------
+__global__ void conf_max_kernel(const float *__restrict__ conf, const int *__restrict__ count, int cap,
+                                unsigned int *__restrict__ max_bits)
+{
+    const int f = blockIdx.x, n = count[f];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, conf[(long)f * cap + i]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    // confidences that passed the 0.55 floor are positive: their bit patterns order like the floats
+    if ((threadIdx.x & 63) == 0) atomicMax(max_bits, __float_as_uint(m));
+}
+
+__global__ void obs_cost_kernel(const float *__restrict__ conf, const int *__restrict__ count, int cap, int method,
+                                double max_cost, const unsigned int *__restrict__ max_bits, double *__restrict__ cost)
+{
+    const int f = blockIdx.x, n = count[f];
+    const double cmax = (double)__uint_as_float(*max_bits);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        double s = (double)conf[(long)f * cap + i];          // python float of the f32 value (:653)
+        if (method == 0) s = s / cmax;                        // 'scale_to_max' (:658-659)
+        else if (s > 1.0) s = 1.0;                            // 'ceil' (:656-657)
+        double beta = (s - 1.0) * -1.0 + 1e-6;                // mincostflow_models.py:23
+        double c = log(beta / (1.0 - beta));                  // :24
+        if (c > max_cost) c = max_cost;                       // :25-26
+        if (c < -max_cost) c = -max_cost;
+        cost[(long)f * cap + i] = c;
+    }
+}
+
+// ---- arc list ----------------------------------------------------------------------------------
+// integer arc cost = cost_units << 16 | hash16(kind, a, b): same formula as axt_arc_cost_int (api.cpp)
+__device__ __forceinline__ long arc_cost_int(long units, int kind, long a, long b)
+{
+    unsigned long x = ((unsigned long)kind << 60) ^ ((unsigned long)a << 30) ^ (unsigned long)b;
+    x += 0x9E3779B97F4A7C15ul;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ul;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBul;
+    x ^= x >> 31;
+    return units * 65536 + (long)(x & 0xFFFFul);
+}
+
+// frame_off[t] = number of detections in frames < t (single block; n_frames is a few thousand at most)
+__global__ void frame_offsets_kernel(const int *__restrict__ count, int n_frames, int cap, int *__restrict__ frame_off)
+{
+    __shared__ int carry;
+    __shared__ int buf[1024];
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n_frames; base += 1024) {
+        const int i = base + threadIdx.x;
+        int v = (i < n_frames) ? min(count[i], cap) : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            int t = (threadIdx.x >= o) ? buf[threadIdx.x - o] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < n_frames) frame_off[i] = carry + buf[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += buf[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) frame_off[n_frames] = carry;
+}
+
+// One wave per (source detection a of frame t, gap g): scans the detections of frame t+g, 64 per step.
+// FILL == false: writes the number of admitted targets to cnt[(a_global)*max_gap + g-1].
+// FILL == true : writes the arcs at row_ptr[a_global] + (arcs of smaller gaps) in ascending b.
+template <bool FILL>
+__global__ __launch_bounds__(256) void arcs_open_kernel(
+    const int *__restrict__ x, const int *__restrict__ y, const int *__restrict__ count,
+    const int *__restrict__ frame_off, int n_frames, int cap, int H, int W, int max_dist, int conn8, int max_gap,
+    const int *__restrict__ dmax, int *__restrict__ cnt, const long *__restrict__ row_ptr,
+    int *__restrict__ col, short *__restrict__ len, unsigned char *__restrict__ gapv,
+    const long *__restrict__ cost_units, long *__restrict__ cost)
+{
+    const int t = blockIdx.x;
+    const int na = min(count[t], cap);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
+    for (int w = blockIdx.y * waves + wave; w < na * max_gap; w += gridDim.y * waves) {
+        const int i = w / max_gap, g = w % max_gap + 1;
+        const int a = frame_off[t] + i;
+        const int tb = t + g;
+        int total = 0;
+        if (tb < n_frames) {
+            const int nb = min(count[tb], cap);
+            const int xa = x[(long)t * cap + i], ya = y[(long)t * cap + i];
+            const int lim = dmax[g - 1];
+            long base = 0;
+            if (FILL) {
+                base = row_ptr[a];
+                for (int gg = 1; gg < g; ++gg) base += cnt[(long)a * max_gap + gg - 1];
+            }
+            for (int j0 = 0; j0 < nb; j0 += 64) {
+                const int j = j0 + lane;
+                int d = max_dist;
+                if (j < nb) d = path_len_open(xa, ya, x[(long)tb * cap + j], y[(long)tb * cap + j], H, W, max_dist, conn8);
+                const bool ok = (j < nb) && (d <= lim);
+                const unsigned long long m = __ballot(ok);
+                if (FILL && ok) {
+                    const long o = base + total + __popcll(m & ((1ull << lane) - 1ull));
+                    col[o] = frame_off[tb] + j;
+                    len[o] = (short)d;
+                    gapv[o] = (unsigned char)g;
+                    if (cost) cost[o] = arc_cost_int(cost_units[(long)(g - 1) * (max_dist + 1) + d], 3, a, frame_off[tb] + j);
+                }
+                total += __popcll(m);
+            }
+        }
+        if (!FILL && lane == 0) cnt[(long)a * max_gap + g - 1] = total;
+    }
+}
+
+// row_ptr = exclusive scan of the per-detection arc counts (single block, sequential over chunks)
+__global__ void row_ptr_kernel(const int *__restrict__ cnt, const int *__restrict__ frame_off, int n_frames, int max_gap,
+                               long *__restrict__ row_ptr)
+{
+    __shared__ long carry;
+    __shared__ long buf[1024];
+    const int n_det = frame_off[n_frames];
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n_det; base += 1024) {
+        const int i = base + threadIdx.x;
+        long v = 0;
+        if (i < n_det)
+            for (int g = 0; g < max_gap; ++g) v += cnt[(long)i * max_gap + g];
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            long t = (threadIdx.x >= o) ? buf[threadIdx.x - o] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < n_det) row_ptr[i] = carry + buf[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += buf[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) row_ptr[n_det] = carry;
+}
+
+}  // namespace
+
+extern "C" {
+
+int axt_obs_costs(const float *d_conf, const int32_t *d_count, int n_frames, int cap, int method, double max_conf_cost,
+                  double *d_cost, void *stream)
+{
+    AXT_REQUIRE(d_conf && d_count && d_cost, "null argument");
+    AXT_REQUIRE(method == 0 || method == 1, "method must be 0 (scale_to_max) or 1 (ceil)");
+    if (n_frames <= 0) return AXT_OK;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned int *mx = nullptr;
+    AXT_CHECK_HIP(hipMallocAsync((void **)&mx, sizeof(unsigned int), st));
+    AXT_CHECK_HIP(hipMemsetAsync(mx, 0, sizeof(unsigned int), st));
+    hipLaunchKernelGGL(conf_max_kernel, dim3(n_frames), dim3(64), 0, st, d_conf, d_count, cap, mx);
+    AXT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(obs_cost_kernel, dim3(n_frames), dim3(64), 0, st, d_conf, d_count, cap, method, max_conf_cost,
+                       mx, d_cost);
+    AXT_LAUNCH_CHECK();
+    AXT_CHECK_HIP(hipFreeAsync(mx, st));
+    return AXT_OK;
+}
+
+int axt_path_cost(const int32_t *d_xa, const int32_t *d_ya, int na, const int32_t *d_xb, const int32_t *d_yb, int nb,
+                  const uint8_t *d_mask, int H, int W, int max_dist, int conn8, int32_t *d_D, void *stream)
+{
+    AXT_REQUIRE(na >= 0 && nb >= 0 && H > 0 && W > 0 && max_dist > 0 && max_dist < 32768, "bad argument");
+    if ((long)na * nb == 0) return AXT_OK;
+    AXT_REQUIRE(d_xa && d_ya && d_xb && d_yb && d_D, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (d_mask) return axt_path_cost_masked(d_xa, d_ya, na, d_xb, d_yb, nb, d_mask, H, W, max_dist, conn8, d_D, st);
+    const long n = (long)na * nb;
+    hipLaunchKernelGGL(path_cost_open_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_xa, d_ya, na, d_xb,
+                       d_yb, nb, H, W, max_dist, conn8, d_D);
+    AXT_LAUNCH_CHECK();
+    return AXT_OK;
+}
+
+int axt_build_arcs(const int32_t *d_x, const int32_t *d_y, const int32_t *d_count, int n_frames, int cap,
+                   const uint8_t *d_mask, int H, int W, int max_dist, int conn8, int max_gap, const int32_t *h_dmax,
+                   int64_t *d_row_ptr, int32_t *d_work, int32_t *d_col, int16_t *d_len, uint8_t *d_gap,
+                   const int64_t *d_cost_units, int64_t *d_cost, int64_t *n_arcs, void *stream)
+{
+    AXT_REQUIRE(d_x && d_y && d_count && h_dmax && d_row_ptr && d_work && n_arcs, "null argument");
+    AXT_REQUIRE(n_frames >= 1 && cap >= 1 && max_gap >= 1 && max_gap <= 8, "bad argument");
+    AXT_REQUIRE(d_mask == nullptr, "axt_build_arcs: masked grids go through axt_path_cost (see DESIGN.md)");
+    hipStream_t st = (hipStream_t)stream;
+    // d_work layout: cnt [n_frames*cap*max_gap] | frame_off [n_frames+1] | dmax [max_gap]
+    int *cnt = d_work;
+    int *frame_off = d_work + (size_t)n_frames * cap * max_gap;
+    int *dmax = frame_off + n_frames + 1;
+    const dim3 grid(n_frames, 8), block(256);
+    if (d_col == nullptr) {
+        AXT_CHECK_HIP(hipMemcpyAsync(dmax, h_dmax, sizeof(int) * max_gap, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(frame_offsets_kernel, dim3(1), dim3(1024), 0, st, d_count, n_frames, cap, frame_off);
+        AXT_LAUNCH_CHECK();
+        hipLaunchKernelGGL(arcs_open_kernel<false>, grid, block, 0, st, d_x, d_y, d_count, frame_off, n_frames, cap, H,
+                           W, max_dist, conn8, max_gap, dmax, cnt, (const long *)nullptr, (int *)nullptr,
+                           (short *)nullptr, (unsigned char *)nullptr, (const long *)nullptr, (long *)nullptr);
+        AXT_LAUNCH_CHECK();
+        hipLaunchKernelGGL(row_ptr_kernel, dim3(1), dim3(1024), 0, st, cnt, frame_off, n_frames, max_gap,
+                           (long *)d_row_ptr);
+        AXT_LAUNCH_CHECK();
+        int n_det = 0;
+        AXT_CHECK_HIP(hipMemcpyAsync(&n_det, frame_off + n_frames, sizeof(int), hipMemcpyDeviceToHost, st));
+        AXT_CHECK_HIP(hipStreamSynchronize(st));
+        long total = 0;
+        AXT_CHECK_HIP(hipMemcpyAsync(&total, (long *)d_row_ptr + n_det, sizeof(long), hipMemcpyDeviceToHost, st));
+        AXT_CHECK_HIP(hipStreamSynchronize(st));
+        *n_arcs = total;
+        return AXT_OK;
+    }
+    AXT_REQUIRE(d_len && d_gap, "null argument");
+    AXT_REQUIRE((d_cost == nullptr) == (d_cost_units == nullptr), "d_cost and d_cost_units go together");
+    hipLaunchKernelGGL(arcs_open_kernel<true>, grid, block, 0, st, d_x, d_y, d_count, frame_off, n_frames, cap, H, W,
+                       max_dist, conn8, max_gap, dmax, cnt, (const long *)d_row_ptr, d_col, d_len, d_gap,
+                       (const long *)d_cost_units, (long *)d_cost);
+    AXT_LAUNCH_CHECK();
+    return AXT_OK;
+}
+
+}  // extern "C"

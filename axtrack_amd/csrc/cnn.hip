@@ -1,0 +1,612 @@
+// Detector forward pass for gfx950 (MI355X): YOLO_AXTrack (reference axtrack/machinelearning/model.py:20-125)
+// as f32-in / f32-accumulate MFMA kernels.
+//
+//   conv3x3_mfma   implicit-GEMM 3x3 convolution (pad 1, stride 1|2) + folded BatchNorm + LeakyReLU(0.1)
+//                  (+ fused MaxPool2d(2,2)); the input patch and a K-chunk of the weights are staged in LDS,
+//                  v_mfma_f32_16x16x4_f32 accumulates 16 pixels x 16 channels per instruction.
+//                  The first layer reads the 5-frame temporal stack straight from the timelapse
+//                  (fuses Timelapse.get_frametiles_stack, Timelapse.py:111-125,150-157).
+//   gemm_mfma      split-K GEMM for the three linear layers, partial slabs reduced in a fixed order
+//                  (bit-reproducible) by reduce_bias_act (+ Sigmoid).
+//
+// Numerics: f32 MFMA on gfx950 is a k-ordered chain of f32 FMAs (exact f32, no reduced precision).
+// BatchNorm is folded in f64 at pack time and rounded once to f32.
+#include "axt_common.h"
+
+#include <math.h>
+#include <stdlib.h>
+
+#include <vector>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// network description (deployed ARCHITECTURE, deployed_model/params.txt:34)
+// ------------------------------------------------------------------------------------------------
+struct ConvSpec { int cin, cout, stride, pool, hin; };
+static const ConvSpec kConv[8] = {
+    {5, 20, 2, 0, 512}, {20, 40, 2, 0, 256}, {40, 80, 1, 1, 128}, {80, 80, 1, 0, 64},
+    {80, 80, 1, 1, 64}, {80, 80, 1, 0, 32},  {80, 80, 1, 1, 32},  {80, 160, 1, 0, 16}};
+constexpr int kFeat = 160 * 16 * 16;   // 40960
+constexpr int kFc = 1024;
+constexpr int kOut = AXT_YOLO_FLOATS;  // 432
+constexpr int kOutPad = 448;           // 7 x 64
+
+// ------------------------------------------------------------------------------------------------
+// conv kernel geometry (compile time)
+// ------------------------------------------------------------------------------------------------
+template <int STRIDE, int MT>
+struct Geo {
+    static constexpr int TW = 16, TH = 4 * MT;
+    static constexpr int PH = (TH - 1) * STRIDE + 3, PW = (TW - 1) * STRIDE + 3;
+    // plane stride: stride-1 reads want lanes 16..31 (next channel) 16 banks away; stride-2 reads
+    // touch every other bank, the next channel must land on the odd ones
+    static constexpr int RAW = PH * PW;
+    static constexpr int PLANE = (STRIDE == 1) ? (RAW + ((16 - RAW % 32) + 32) % 32) : (RAW | 1);
+};
+constexpr int npadw(int nt) { return (nt % 2) ? nt * 16 : nt * 16 + 16; }   // row stride == 16 (mod 32)
+
+struct TileList { int n; short yx[2 * 256]; };
+
+// first layer: K index k -> offset of (c, ky, kx) inside the LDS patch, k = c*9 + ky*3 + kx (k < 45)
+template <int PLANE, int PW>
+__device__ __forceinline__ int first_koff(int k)
+{
+    if (k >= 45) return 0;   // zero weights there
+    const int c = k / 9, r = k % 9;
+    return c * PLANE + (r / 3) * PW + (r % 3);
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv3x3 + folded BN + LeakyReLU (+ maxpool 2x2)
+//   grid: x = spatial tiles (tiles_x * tiles_y), y = output-channel group, z = batch item
+//   block: 256 threads = 4 waves; wave w owns rows [w*MT, (w+1)*MT) of the TH x 16 output tile and all
+//   NT*16 channels of the group: MT x NT accumulator tiles of 16 px x 16 ch.
+// ------------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int STRIDE, bool POOL, int CCH, int MT, int NT, bool FIRST>
+__global__ __launch_bounds__(256) void conv3x3_mfma(
+    const float *__restrict__ in,       // FIRST: frames [T_all,Hf,Wf]; else activations [B,CIN,Hin,Win]
+    const float *__restrict__ wpk,      // packed weights [ngroup][nchunk][KROWS][NPADW]
+    const float *__restrict__ bias,     // folded bias [COUT]
+    float *__restrict__ out,            // [B,COUT,Hout,Wout]
+    int Hin, int Win, int tiles_x,
+    int Hf, int Wf, int t0, int tstep, int item0, int n_tiles, TileList tl)
+{
+    using G = Geo<STRIDE, MT>;
+    constexpr int PH = G::PH, PW = G::PW, PLANE = G::PLANE, TH = G::TH;
+    constexpr int NPADW = npadw(NT);
+    constexpr int NCHUNK = FIRST ? 1 : CIN / CCH;
+    constexpr int KSTEPS = FIRST ? 12 : 9 * CCH / 4;       // k-steps of 4 per chunk
+    constexpr int KROWS = KSTEPS * 4;
+    static_assert(FIRST || CIN % CCH == 0, "CIN must be a multiple of CCH");
+    static_assert(CCH % 4 == 0, "CCH must be a multiple of 4");
+    static_assert(!POOL || MT % 2 == 0, "pooling pairs rows inside a wave");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *patch = smem;                          // [CCH][PLANE]
+    float *wl = smem + ((CCH * PLANE + 3) & ~3);   // [KROWS][NPADW]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 15, q = lane >> 4;
+    const int b = blockIdx.z, grp = blockIdx.y;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
+    const int y0 = ty * TH, x0 = tx * 16;                 // output tile origin (before pooling)
+    const int iy0 = y0 * STRIDE - 1, ix0 = x0 * STRIDE - 1;
+
+    // where this item's input lives
+    const float *src;
+    int lim_y, lim_x;        // valid input rows/cols are [0, lim)
+    long cstride;            // channel stride in elements
+    int rstride;
+    if constexpr (FIRST) {
+        const int item = item0 + b;
+        const int t = t0 + (item / n_tiles) * tstep, k = item % n_tiles;
+        const int oy = tl.yx[2 * k] * AXT_TILE, ox = tl.yx[2 * k + 1] * AXT_TILE;
+        src = in + ((long)t * Hf + oy) * Wf + ox;
+        cstride = (long)Hf * Wf;
+        rstride = Wf;
+        lim_y = min(AXT_TILE, Hf - oy);
+        lim_x = min(AXT_TILE, Wf - ox);
+    } else {
+        src = in + (long)b * CIN * Hin * Win;
+        cstride = (long)Hin * Win;
+        rstride = Win;
+        lim_y = Hin;
+        lim_x = Win;
+    }
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int koff[FIRST ? KSTEPS : 1];
+    if constexpr (FIRST) {
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) koff[s] = first_koff<PLANE, PW>(s * 4 + q);
+    }
+
+    const int a_base = (FIRST ? 0 : q * PLANE) + (wave * MT * STRIDE) * PW + p * STRIDE;
+    const int b_base = q * NPADW + p;
+    const float *wsrc = wpk + (long)grp * NCHUNK * KROWS * NPADW;
+
+    for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+        if (chunk) __syncthreads();
+        // ---- stage the input patch: CCH (FIRST: 5) channels x PH x PW, zero outside the image
+        constexpr int NPC = FIRST ? CIN : CCH;
+        for (int e = tid; e < NPC * PH * PW; e += 256) {
+            const int c = e / (PH * PW), rem = e - c * (PH * PW);
+            const int r = rem / PW, col = rem - r * PW;
+            const int gy = iy0 + r, gx = ix0 + col;
+            float v = 0.f;
+            if (gy >= 0 && gy < lim_y && gx >= 0 && gx < lim_x)
+                v = src[(long)(chunk * CCH + c) * cstride + (long)gy * rstride + gx];
+            patch[c * PLANE + r * PW + col] = v;
+        }
+        // ---- stage this chunk's weights (contiguous, 16 B per lane)
+        {
+            const f32x4 *w4 = reinterpret_cast<const f32x4 *>(wsrc + (long)chunk * KROWS * NPADW);
+            f32x4 *l4 = reinterpret_cast<f32x4 *>(wl);
+            for (int e = tid; e < KROWS * NPADW / 4; e += 256) l4[e] = w4[e];
+        }
+        __syncthreads();
+
+        // ---- MFMA over the chunk
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            float a[MT], bw[NT];
+            if constexpr (FIRST) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) a[m] = patch[a_base + koff[s] + m * STRIDE * PW];
+            } else {
+                constexpr int CG = CCH / 4;
+                const int kk = s / CG, cg = s % CG;      // (ky,kx) major, channel group minor
+                const int ky = kk / 3, kx = kk % 3;
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    a[m] = patch[a_base + cg * 4 * PLANE + (m * STRIDE + ky) * PW + kx];
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bw[n] = wl[b_base + s * 4 * NPADW + n * 16];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bw[n], acc[m][n], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: + folded bias, LeakyReLU(0.1), optional 2x2 max, store NCHW
+    const int Hout = (Hin / STRIDE) / (POOL ? 2 : 1), Wout = (Win / STRIDE) / (POOL ? 2 : 1);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int ch = grp * NT * 16 + n * 16 + p;
+        if (ch >= COUT) continue;
+        const float bv = bias[ch];
+        float *och = out + ((long)b * COUT + ch) * Hout * Wout;
+        if constexpr (!POOL) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                f32x4 v = acc[m][n];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float t = v[j] + bv;
+                    v[j] = t > 0.f ? t : t * 0.1f;
+                }
+                const int row = y0 + wave * MT + m, x = x0 + q * 4;
+                *reinterpret_cast<f32x4 *>(och + (long)row * Wout + x) = v;
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < MT; m += 2) {
+                float v0[4], v1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float t = acc[m][n][j] + bv;
+                    v0[j] = t > 0.f ? t : t * 0.1f;
+                    t = acc[m + 1][n][j] + bv;
+                    v1[j] = t > 0.f ? t : t * 0.1f;
+                }
+                float2 r;
+                r.x = fmaxf(fmaxf(v0[0], v0[1]), fmaxf(v1[0], v1[1]));
+                r.y = fmaxf(fmaxf(v0[2], v0[3]), fmaxf(v1[2], v1[3]));
+                const int row = (y0 + wave * MT + m) >> 1, x = (x0 + q * 4) >> 1;
+                *reinterpret_cast<float2 *>(och + (long)row * Wout + x) = r;
+            }
+        }
+    }
+}
+
+template <int CIN, int COUT, int STRIDE, bool POOL, int CCH, int MT, int NT, bool FIRST>
+constexpr size_t conv_lds_bytes()
+{
+    using G = Geo<STRIDE, MT>;
+    constexpr int KROWS = FIRST ? 48 : 9 * CCH;
+    return (size_t)(((CCH * G::PLANE + 3) & ~3) + KROWS * npadw(NT)) * sizeof(float);
+}
+
+// ------------------------------------------------------------------------------------------------
+// split-K GEMM  slab[z][M][N] = A[M][k0:k1] * B[k0:k1][N]      (A row-major lda, B row-major ldb = N)
+//   block 256 threads = 2x2 waves, block tile 64 x 64, wave tile 32 x 32 (2 x 2 MFMA tiles), BK = 32
+// ------------------------------------------------------------------------------------------------
+constexpr int GBM = 64, GBN = 64, GBK = 32, GLDA = 34, GLDB = 80;
+
+__global__ __launch_bounds__(256) void gemm_mfma(const float *__restrict__ A, int lda,
+                                                 const float *__restrict__ Bm, int N,
+                                                 float *__restrict__ slab, int M, int kper)
+{
+    __shared__ __attribute__((aligned(16))) float As[GBM * GLDA];
+    __shared__ __attribute__((aligned(16))) float Bs[GBK * GLDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 15, q = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n0 = blockIdx.x * GBN, m0 = blockIdx.y * GBM;
+    const int k0 = blockIdx.z * kper;
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // staging assignments: A tile 64 rows x 32 k as float2 (1024 float2 -> 4 per thread)
+    //                      B tile 32 k x 64 n as float4 (512 float4 -> 2 per thread)
+    for (int k = k0; k < k0 + kper; k += GBK) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + i * 256;
+            const int r = e >> 4, c2 = e & 15;
+            int gm = m0 + r;
+            gm = gm < M ? gm : M - 1;
+            const float2 v = *reinterpret_cast<const float2 *>(A + (long)gm * lda + k + c2 * 2);
+            *reinterpret_cast<float2 *>(&As[r * GLDA + c2 * 2]) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + i * 256;
+            const int r = e >> 4, c4 = e & 15;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(Bm + (long)(k + r) * N + n0 + c4 * 4);
+            *reinterpret_cast<f32x4 *>(&Bs[r * GLDB + c4 * 4]) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < GBK / 4; ++s) {
+            float a[2], bw[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = As[(wm * 32 + i * 16 + p) * GLDA + s * 4 + q];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bw[j] = Bs[(s * 4 + q) * GLDB + wn * 32 + j * 16 + p];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bw[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    float *dst = slab + (long)blockIdx.z * M * N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 32 + i * 16 + q * 4 + r, n = n0 + wn * 32 + j * 16 + p;
+                if (m < M) dst[(long)m * N + n] = acc[i][j][r];
+            }
+}
+
+// out[m][n] = act(bias[n] + sum_z slab[z][m][n]), n < Nout (slab rows are N wide), fixed z order
+__global__ void reduce_bias_act(const float *__restrict__ slab, int S, int M, int N, int Nout,
+                                const float *__restrict__ bias, int sigmoid, float *__restrict__ out)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)M * Nout) return;
+    const int m = i / Nout, n = i % Nout;
+    float s = 0.f;
+    for (int z = 0; z < S; ++z) s += slab[((long)z * M + m) * N + n];
+    s += bias[n];
+    if (sigmoid) s = 1.0f / (1.0f + expf(-s));
+    out[(long)m * Nout + n] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct ConvPlan { int cch, nt, ngroups; };
+static const ConvPlan kPlan[8] = {{8, 2, 1}, {4, 3, 1}, {8, 5, 1}, {8, 5, 1}, {8, 5, 1}, {8, 5, 1}, {8, 5, 1}, {8, 5, 2}};
+
+constexpr int kChunkA = 16;       // tile-forwards per launch for the large-activation layers (fits the Infinity Cache)
+constexpr int kFc1Split = 8, kFc2Split = 4, kFc3Split = 4;
+
+}  // namespace
+
+struct axt_detector {
+    int max_batch = 0;
+    float *d_wconv[8] = {};     // packed conv weights
+    float *d_bconv[8] = {};     // folded bias
+    float *d_wfc[3] = {};       // [K][Npad]
+    float *d_bfc[3] = {};
+    float *d_act[8] = {};       // activations after conv block i (chunk-sized for i < 4)
+    float *d_slab = nullptr, *d_fc1 = nullptr, *d_fc2 = nullptr;
+    size_t bytes = 0;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(axt_detector *d, T **p, size_t n)
+{
+    if (hipMalloc((void **)p, n * sizeof(T)) != hipSuccess) {
+        axt_set_error("hipMalloc of %zu bytes failed", n * sizeof(T));
+        return AXT_ENOMEM;
+    }
+    d->bytes += n * sizeof(T);
+    return AXT_OK;
+}
+
+// Packs one conv block: folds BN (f64), lays weights out as [group][chunk][krow][NPADW].
+// krow order inside a chunk: ((ky*3+kx) * CCH/4 + cg) * 4 + kk  <->  channel chunk*CCH + cg*4 + kk
+// first layer: krow = c*9 + ky*3 + kx (45 rows, padded to 48).
+void pack_conv(int li, const float *w, const float *b, const float *gamma, const float *beta,
+               const float *mean, const float *var, std::vector<float> &wp, std::vector<float> &bp)
+{
+    const ConvSpec &cs = kConv[li];
+    const ConvPlan &pl = kPlan[li];
+    const int NPADW = npadw(pl.nt);
+    const bool first = li == 0;
+    const int nchunk = first ? 1 : cs.cin / pl.cch;
+    const int krows = first ? 48 : 9 * pl.cch;
+    wp.assign((size_t)pl.ngroups * nchunk * krows * NPADW, 0.f);
+    bp.assign(cs.cout, 0.f);
+    for (int co = 0; co < cs.cout; ++co) {
+        const double sc = (double)gamma[co] / sqrt((double)var[co] + 1e-5);
+        bp[co] = (float)(((double)b[co] - (double)mean[co]) * sc + (double)beta[co]);
+        const int grp = co / (pl.nt * 16), col = co % (pl.nt * 16);
+        for (int ci = 0; ci < cs.cin; ++ci)
+            for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float v = (float)((double)w[(((size_t)co * cs.cin + ci) * 3 + ky) * 3 + kx] * sc);
+                    int chunk, krow;
+                    if (first) {
+                        chunk = 0;
+                        krow = ci * 9 + ky * 3 + kx;
+                    } else {
+                        chunk = ci / pl.cch;
+                        const int c = ci % pl.cch;
+                        krow = ((ky * 3 + kx) * (pl.cch / 4) + c / 4) * 4 + c % 4;
+                    }
+                    wp[(((size_t)grp * nchunk + chunk) * krows + krow) * NPADW + col] = v;
+                }
+    }
+}
+
+template <int CIN, int COUT, int STRIDE, bool POOL, int CCH, int MT, int NT, bool FIRST>
+int launch_conv(const float *in, const float *w, const float *bias, float *out, int Hin, int ngroups, int B,
+                hipStream_t st, int Hf = 0, int Wf = 0, int t0 = 0, int tstep = 1, int item0 = 0, int n_tiles = 1,
+                const TileList *tl = nullptr)
+{
+    auto kern = conv3x3_mfma<CIN, COUT, STRIDE, POOL, CCH, MT, NT, FIRST>;
+    constexpr size_t lds = conv_lds_bytes<CIN, COUT, STRIDE, POOL, CCH, MT, NT, FIRST>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        AXT_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int Hpre = Hin / STRIDE;                 // output size before pooling
+    const int TH = 4 * MT;
+    AXT_REQUIRE(Hpre % TH == 0 && Hpre % 16 == 0, "conv: output %d not a multiple of the tile", Hpre);
+    const int tiles_x = Hpre / 16, tiles_y = Hpre / TH;
+    TileList dummy;
+    dummy.n = 0;
+    dim3 grid(tiles_x * tiles_y, ngroups, B);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, in, w, bias, out, Hin, Hin, tiles_x, Hf, Wf, t0, tstep,
+                       item0, n_tiles, tl ? *tl : dummy);
+    AXT_LAUNCH_CHECK();
+    return AXT_OK;
+}
+
+int launch_gemm(const float *A, int lda, const float *Bm, int N, float *slab, int M, int K, int split,
+                hipStream_t st)
+{
+    AXT_REQUIRE(N % GBN == 0 && K % (split * GBK) == 0, "gemm: bad shape N=%d K=%d split=%d", N, K, split);
+    dim3 grid(N / GBN, axt_cdiv(M, GBM), split);
+    hipLaunchKernelGGL(gemm_mfma, grid, dim3(256), 0, st, A, lda, Bm, N, slab, M, K / split);
+    AXT_LAUNCH_CHECK();
+    return AXT_OK;
+}
+
+int launch_reduce(const float *slab, int S, int M, int N, int Nout, const float *bias, int sig, float *out,
+                  hipStream_t st)
+{
+    const long n = (long)M * Nout;
+    hipLaunchKernelGGL(reduce_bias_act, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, S, M, N, Nout,
+                       bias, sig, out);
+    AXT_LAUNCH_CHECK();
+    return AXT_OK;
+}
+
+// layers 0..4 (large activations) for up to kChunkA items
+int run_front(axt_detector *d, const float *frames, int Hf, int Wf, int t0, int tstep, int item0, int n_tiles,
+              const TileList &tl, int nb, float *act4_out, hipStream_t st)
+{
+    int rc;
+    if ((rc = launch_conv<5, 20, 2, false, 8, 4, 2, true>(frames, d->d_wconv[0], d->d_bconv[0], d->d_act[0], 512, 1,
+                                                          nb, st, Hf, Wf, t0, tstep, item0, n_tiles, &tl))) return rc;
+    if ((rc = launch_conv<20, 40, 2, false, 4, 4, 3, false>(d->d_act[0], d->d_wconv[1], d->d_bconv[1], d->d_act[1],
+                                                            256, 1, nb, st))) return rc;
+    if ((rc = launch_conv<40, 80, 1, true, 8, 4, 5, false>(d->d_act[1], d->d_wconv[2], d->d_bconv[2], d->d_act[2],
+                                                           128, 1, nb, st))) return rc;
+    if ((rc = launch_conv<80, 80, 1, false, 8, 4, 5, false>(d->d_act[2], d->d_wconv[3], d->d_bconv[3], d->d_act[3],
+                                                            64, 1, nb, st))) return rc;
+    if ((rc = launch_conv<80, 80, 1, true, 8, 4, 5, false>(d->d_act[3], d->d_wconv[4], d->d_bconv[4], act4_out, 64,
+                                                           1, nb, st))) return rc;
+    return AXT_OK;
+}
+
+// layers 5..7 + the three linear layers for nb items whose block-4 output is in d_act[4]
+int run_back(axt_detector *d, int nb, float *d_yolo, hipStream_t st)
+{
+    int rc;
+    if ((rc = launch_conv<80, 80, 1, false, 8, 4, 5, false>(d->d_act[4], d->d_wconv[5], d->d_bconv[5], d->d_act[5],
+                                                            32, 1, nb, st))) return rc;
+    if ((rc = launch_conv<80, 80, 1, true, 8, 4, 5, false>(d->d_act[5], d->d_wconv[6], d->d_bconv[6], d->d_act[6],
+                                                           32, 1, nb, st))) return rc;
+    if ((rc = launch_conv<80, 160, 1, false, 8, 4, 5, false>(d->d_act[6], d->d_wconv[7], d->d_bconv[7], d->d_act[7],
+                                                             16, 2, nb, st))) return rc;
+    if ((rc = launch_gemm(d->d_act[7], kFeat, d->d_wfc[0], kFc, d->d_slab, nb, kFeat, kFc1Split, st))) return rc;
+    if ((rc = launch_reduce(d->d_slab, kFc1Split, nb, kFc, kFc, d->d_bfc[0], 1, d->d_fc1, st))) return rc;
+    if ((rc = launch_gemm(d->d_fc1, kFc, d->d_wfc[1], kFc, d->d_slab, nb, kFc, kFc2Split, st))) return rc;
+    if ((rc = launch_reduce(d->d_slab, kFc2Split, nb, kFc, kFc, d->d_bfc[1], 1, d->d_fc2, st))) return rc;
+    if ((rc = launch_gemm(d->d_fc2, kFc, d->d_wfc[2], kOutPad, d->d_slab, nb, kFc, kFc3Split, st))) return rc;
+    if ((rc = launch_reduce(d->d_slab, kFc3Split, nb, kOutPad, kOut, d->d_bfc[2], 0, d_yolo, st))) return rc;
+    return AXT_OK;
+}
+
+int forward_items(axt_detector *d, const float *frames, int Hf, int Wf, int t0, int tstep, int n_items, int n_tiles,
+                  const TileList &tl, float *d_yolo, hipStream_t st)
+{
+    for (int base = 0; base < n_items; base += d->max_batch) {
+        const int nb = (n_items - base < d->max_batch) ? n_items - base : d->max_batch;
+        for (int c = 0; c < nb; c += kChunkA) {
+            const int nc = (nb - c < kChunkA) ? nb - c : kChunkA;
+            const int rc = run_front(d, frames, Hf, Wf, t0, tstep, base + c, n_tiles, tl, nc,
+                                     d->d_act[4] + (size_t)c * 80 * 32 * 32, st);
+            if (rc) return rc;
+        }
+        const int rc = run_back(d, nb, d_yolo + (size_t)base * kOut, st);
+        if (rc) return rc;
+    }
+    return AXT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+double axt_cnn_flops_per_tile(void)
+{
+    double f = 0;
+    for (const ConvSpec &c : kConv) {
+        const double ho = c.hin / c.stride;
+        f += 2.0 * ho * ho * c.cout * c.cin * 9;
+    }
+    f += 2.0 * kFeat * kFc + 2.0 * kFc * kFc + 2.0 * kFc * kOut;
+    return f;
+}
+
+int axt_detector_create(const float *const *h_tensors, int n_tensors, int max_batch, axt_detector **out)
+{
+    AXT_REQUIRE(h_tensors && out, "null argument");
+    AXT_REQUIRE(n_tensors == AXT_N_WEIGHT_TENSORS, "expected %d tensors, got %d", AXT_N_WEIGHT_TENSORS, n_tensors);
+    AXT_REQUIRE(max_batch >= 1 && max_batch <= 65535, "max_batch %d out of range", max_batch);
+    for (int i = 0; i < n_tensors; ++i) AXT_REQUIRE(h_tensors[i] != nullptr, "tensor %d is null", i);
+    axt_detector *d = new (std::nothrow) axt_detector();
+    if (!d) return AXT_ENOMEM;
+    d->max_batch = max_batch;
+    int rc = AXT_OK;
+    std::vector<float> wp, bp;
+    for (int li = 0; li < 8 && !rc; ++li) {
+        const float *const *t = h_tensors + li * 6;
+        pack_conv(li, t[0], t[1], t[2], t[3], t[4], t[5], wp, bp);
+        if ((rc = dev_alloc(d, &d->d_wconv[li], wp.size()))) break;
+        if ((rc = dev_alloc(d, &d->d_bconv[li], bp.size()))) break;
+        if (hipMemcpy(d->d_wconv[li], wp.data(), wp.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d->d_bconv[li], bp.data(), bp.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            axt_set_error("weight upload failed (conv block %d)", li);
+            rc = AXT_EHIP;
+        }
+    }
+    // linear layers: reference stores [out,in]; the GEMM wants [in][out_padded]
+    const int fin[3] = {kFeat, kFc, kFc}, fout[3] = {kFc, kFc, kOut}, fpad[3] = {kFc, kFc, kOutPad};
+    for (int l = 0; l < 3 && !rc; ++l) {
+        const float *w = h_tensors[48 + 2 * l], *b = h_tensors[48 + 2 * l + 1];
+        std::vector<float> wt((size_t)fin[l] * fpad[l], 0.f);
+        for (int o = 0; o < fout[l]; ++o)
+            for (int i = 0; i < fin[l]; ++i) wt[(size_t)i * fpad[l] + o] = w[(size_t)o * fin[l] + i];
+        if ((rc = dev_alloc(d, &d->d_wfc[l], wt.size()))) break;
+        if ((rc = dev_alloc(d, &d->d_bfc[l], (size_t)fout[l]))) break;
+        if (hipMemcpy(d->d_wfc[l], wt.data(), wt.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d->d_bfc[l], b, (size_t)fout[l] * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            axt_set_error("weight upload failed (linear %d)", l);
+            rc = AXT_EHIP;
+        }
+    }
+    // activations
+    const size_t per_item[8] = {20u * 256 * 256, 40u * 128 * 128, 80u * 64 * 64, 80u * 64 * 64,
+                                80u * 32 * 32,   80u * 32 * 32,   80u * 16 * 16, 160u * 16 * 16};
+    for (int i = 0; i < 8 && !rc; ++i)
+        rc = dev_alloc(d, &d->d_act[i], per_item[i] * (size_t)(i < 4 ? kChunkA : max_batch));
+    if (!rc) rc = dev_alloc(d, &d->d_slab, (size_t)kFc1Split * max_batch * kFc);
+    if (!rc) rc = dev_alloc(d, &d->d_fc1, (size_t)max_batch * kFc);
+    if (!rc) rc = dev_alloc(d, &d->d_fc2, (size_t)max_batch * kFc);
+    if (!rc && hipDeviceSynchronize() != hipSuccess) {
+        axt_set_error("device synchronize failed after upload");
+        rc = AXT_EHIP;
+    }
+    if (rc) {
+        axt_detector_destroy(d);
+        return rc;
+    }
+    *out = d;
+    return AXT_OK;
+}
+
+void axt_detector_destroy(axt_detector *d)
+{
+    if (!d) return;
+    for (int i = 0; i < 8; ++i) {
+        (void)hipFree(d->d_wconv[i]);
+        (void)hipFree(d->d_bconv[i]);
+        (void)hipFree(d->d_act[i]);
+    }
+    for (int i = 0; i < 3; ++i) {
+        (void)hipFree(d->d_wfc[i]);
+        (void)hipFree(d->d_bfc[i]);
+    }
+    (void)hipFree(d->d_slab);
+    (void)hipFree(d->d_fc1);
+    (void)hipFree(d->d_fc2);
+    delete d;
+}
+
+size_t axt_detector_device_bytes(const axt_detector *d) { return d ? d->bytes : 0; }
+
+int axt_cnn_forward(axt_detector *det, const float *d_x, int B, float *d_yolo, void *stream)
+{
+    AXT_REQUIRE(det && d_x && d_yolo, "null argument");
+    AXT_REQUIRE(B >= 0, "negative batch");
+    if (B == 0) return AXT_OK;
+    // X[B,5,512,512] is a timelapse of 5*B frames of 512x512 in which item b reads frames 5b..5b+4:
+    // the frames path with a frame step of 5 and a single tile at the origin.
+    TileList tl;
+    tl.n = 1;
+    tl.yx[0] = 0;
+    tl.yx[1] = 0;
+    return forward_items(det, d_x, AXT_TILE, AXT_TILE, 0, AXT_IN_CH, B, 1, tl, d_yolo, (hipStream_t)stream);
+}
+
+int axt_cnn_forward_frames(axt_detector *det, const float *d_frames, int T_all, int H, int W, int t0, int n_frames,
+                           const int32_t *h_tile_yx, int n_tiles, float *d_yolo, void *stream)
+{
+    AXT_REQUIRE(det && d_frames && d_yolo && h_tile_yx, "null argument");
+    AXT_REQUIRE(n_tiles >= 1 && n_tiles <= 256, "n_tiles %d out of range [1,256]", n_tiles);
+    AXT_REQUIRE(t0 >= 0 && n_frames >= 0 && t0 + n_frames + 4 <= T_all, "frames [%d,%d) + context exceed T_all=%d",
+                t0, t0 + n_frames, T_all);
+    TileList tl;
+    tl.n = n_tiles;
+    for (int k = 0; k < n_tiles; ++k) {
+        const int ty = h_tile_yx[2 * k], tx = h_tile_yx[2 * k + 1];
+        AXT_REQUIRE(ty >= 0 && tx >= 0 && ty * AXT_TILE < H && tx * AXT_TILE < W, "tile %d (%d,%d) outside %dx%d", k,
+                    ty, tx, H, W);
+        tl.yx[2 * k] = (short)ty;
+        tl.yx[2 * k + 1] = (short)tx;
+    }
+    if (n_frames == 0) return AXT_OK;
+    return forward_items(det, d_frames, H, W, t0, 1, n_frames * n_tiles, n_tiles, tl, d_yolo, (hipStream_t)stream);
+}
+
+}  // extern "C"

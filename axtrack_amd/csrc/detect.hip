@@ -1,0 +1,202 @@
+// YOLO grid -> per-frame detections on gfx950, plus the tile-occupancy scan.
+//
+// Replaces the per-frame pandas pipeline of AxonDetections.detect_dataset
+// (reference axtrack/AxonDetections.py:111-133):
+//   _yolo_Y2pandas_det (:178-248)  ->  decode + threshold
+//   Timelapse.stitch_tiles (Timelapse.py:166-197)  ->  + tile origin
+//   _non_max_supression (:250-278)  ->  greedy centre-distance NMS
+// One workgroup per frame; everything stays in LDS. All arithmetic that decides an integer
+// (anchor rounding, the 0.55 cut, dx^2+dy^2 < 529) is done exactly as the reference does it.
+#include "axt_common.h"
+
+namespace {
+
+struct TileOrigins { int n; short yx[2 * 256]; };
+
+// ------------------------------------------------------------------------------------------------
+// tile occupancy: occ[tile] = any(frames[:, tile] > 0)        (Timelapse.py:551-558)
+// grid: (rows of the frame, T_all); block: 256 threads striding over x
+// ------------------------------------------------------------------------------------------------
+__global__ void tile_occupancy_kernel(const float *__restrict__ frames, int H, int W, int ntx,
+                                      unsigned int *__restrict__ occ_words)
+{
+    const int y = blockIdx.x, t = blockIdx.y;
+    const float *row = frames + ((long)t * H + y) * W;
+    const int ty = y / AXT_TILE;
+    for (int tx = 0; tx < ntx; ++tx) {
+        const int x0 = tx * AXT_TILE, x1 = min(W, x0 + AXT_TILE);
+        int any = 0;
+        for (int x = x0 + threadIdx.x; x < x1; x += blockDim.x) any |= (row[x] > 0.f);
+        if (__syncthreads_or(any) && threadIdx.x == 0) atomicOr(&occ_words[ty * ntx + tx], 1u);
+    }
+}
+
+__global__ void occ_words_to_bytes(const unsigned int *__restrict__ w, uint8_t *__restrict__ out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = w[i] ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode + stitch + NMS, one workgroup (256 threads) per frame
+// LDS (dynamic): cand conf/x/y [ncand], sorted conf/x/y [ncand], state [ncand]
+// ------------------------------------------------------------------------------------------------
+constexpr int ST_UNDECIDED = 0, ST_ALIVE = 1, ST_DEAD = 2, ST_DROPPED = 3;
+
+__global__ __launch_bounds__(256) void decode_stitch_nms_kernel(
+    const float *__restrict__ yolo, int n_tiles, TileOrigins tiles, float conf_thr, int thr2, int cap,
+    float *__restrict__ o_conf, int *__restrict__ o_x, int *__restrict__ o_y, int *__restrict__ o_count)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int ncand = n_tiles * AXT_CELLS;
+    float *c_conf = reinterpret_cast<float *>(smem_raw);
+    int *c_x = reinterpret_cast<int *>(c_conf + ncand);
+    int *c_y = c_x + ncand;
+    float *s_conf = reinterpret_cast<float *>(c_y + ncand);
+    int *s_x = reinterpret_cast<int *>(s_conf + ncand);
+    int *s_y = s_x + ncand;
+    int *state = s_y + ncand;
+    __shared__ int n_kept;
+
+    const int frame = blockIdx.x, tid = threadIdx.x;
+    const float *yf = yolo + (long)frame * n_tiles * AXT_YOLO_FLOATS;
+    if (tid == 0) n_kept = 0;
+
+    // ---- decode (AxonDetections.py:192-210) and threshold (:212-220)
+    for (int c = tid; c < ncand; c += 256) {
+        const int k = c / AXT_CELLS, cell = c - k * AXT_CELLS;
+        const int i = cell / AXT_S, j = cell - i * AXT_S;      // dim1 = x cell, dim2 = y cell
+        const float conf = yf[c * 3 + 0], xin = yf[c * 3 + 1], yin = yf[c * 3 + 2];
+        const bool zero = (conf == 0.f) && (xin == 0.f) && (yin == 0.f);
+        // x = round_half_even(((x_in + i) * tilesize) / Sx), all in f32
+        float xf = rintf(__fdiv_rn(__fmul_rn(__fadd_rn(xin, (float)i), (float)AXT_TILE), (float)AXT_S));
+        float yf2 = rintf(__fdiv_rn(__fmul_rn(__fadd_rn(yin, (float)j), (float)AXT_TILE), (float)AXT_S));
+        if (zero) { xf = 0.f; yf2 = 0.f; }
+        c_conf[c] = conf;
+        c_x[c] = (int)xf + tiles.yx[2 * k + 1] * AXT_TILE;      // stitch: Timelapse.py:191-192
+        c_y[c] = (int)yf2 + tiles.yx[2 * k] * AXT_TILE;
+    }
+    __syncthreads();
+
+    // ---- order by descending confidence; ties keep (tile, cell) order. rank by counting.
+    for (int c = tid; c < ncand; c += 256) {
+        const float conf = c_conf[c];
+        if (!(conf >= conf_thr)) continue;                      // NaN fails the comparison, as in torch
+        int rank = 0;
+        for (int o = 0; o < ncand; ++o) {
+            const float oc = c_conf[o];
+            if (!(oc >= conf_thr)) continue;
+            rank += (oc > conf) || (oc == conf && o < c);
+        }
+        s_conf[rank] = conf;
+        s_x[rank] = c_x[c];
+        s_y[rank] = c_y[c];
+        state[rank] = ST_UNDECIDED;
+        atomicAdd(&n_kept, 1);
+    }
+    __syncthreads();
+    const int n = n_kept;
+
+    // ---- greedy NMS (AxonDetections.py:261-274) resolved in parallel rounds: row i dies iff an
+    // earlier ALIVE row lies within dx^2+dy^2 < thr2; it is alive once every earlier row within
+    // that distance is known dead. The fixed point is unique (= the sequential result).
+    for (int round = 0; round <= n; ++round) {
+        int pending_any = 0;
+        for (int i = tid; i < n; i += 256) {
+            if (state[i] != ST_UNDECIDED) continue;
+            const int xi = s_x[i], yi = s_y[i];
+            int st = ST_ALIVE;
+            for (int j = 0; j < i; ++j) {
+                const int dx = s_x[j] - xi, dy = s_y[j] - yi;
+                if (dx * dx + dy * dy < thr2) {
+                    const int sj = state[j];
+                    if (sj == ST_ALIVE) { st = ST_DEAD; break; }
+                    if (sj == ST_UNDECIDED) st = ST_UNDECIDED;
+                }
+            }
+            if (st == ST_UNDECIDED) pending_any = 1;
+            else state[i] = st;
+        }
+        if (!__syncthreads_or(pending_any)) break;
+    }
+    __syncthreads();
+
+    // ---- compact survivors in order (block-wide exclusive scan over `alive`)
+    __shared__ int wave_tot[4];
+    __shared__ int base_sh;
+    if (tid == 0) base_sh = 0;
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + tid;
+        const int alive = (i < n) && (state[i] == ST_ALIVE);
+        const unsigned long long m = __ballot(alive);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[wave] = __popcll(m);
+        __syncthreads();
+        int off = base_sh;
+        for (int w = 0; w < wave; ++w) off += wave_tot[w];
+        if (alive) {
+            const long o = (long)frame * cap + off + before;
+            o_conf[o] = s_conf[i];
+            o_x[o] = s_x[i];
+            o_y[o] = s_y[i];
+        }
+        __syncthreads();
+        if (tid == 0) base_sh += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        __syncthreads();
+    }
+    if (tid == 0) o_count[frame] = base_sh;
+}
+
+}  // namespace
+
+extern "C" {
+
+int axt_tile_occupancy(const float *d_frames, int T_all, int H, int W, uint8_t *d_occ, void *stream)
+{
+    AXT_REQUIRE(d_frames && d_occ, "null argument");
+    AXT_REQUIRE(T_all > 0 && H > 0 && W > 0, "bad shape %dx%dx%d", T_all, H, W);
+    hipStream_t st = (hipStream_t)stream;
+    const int nty = axt_cdiv(H, AXT_TILE), ntx = axt_cdiv(W, AXT_TILE);
+    unsigned int *words = nullptr;
+    AXT_CHECK_HIP(hipMallocAsync((void **)&words, sizeof(unsigned int) * nty * ntx, st));
+    AXT_CHECK_HIP(hipMemsetAsync(words, 0, sizeof(unsigned int) * nty * ntx, st));
+    hipLaunchKernelGGL(tile_occupancy_kernel, dim3(H, T_all), dim3(256), 0, st, d_frames, H, W, ntx, words);
+    AXT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(occ_words_to_bytes, dim3(axt_cdiv(nty * ntx, 256)), dim3(256), 0, st, words, d_occ, nty * ntx);
+    AXT_LAUNCH_CHECK();
+    AXT_CHECK_HIP(hipFreeAsync(words, st));
+    return AXT_OK;
+}
+
+int axt_decode_stitch_nms(const float *d_yolo, int n_frames, int n_tiles, const int32_t *h_tile_yx, float conf_thr,
+                          int min_dist, int cap, float *d_conf, int32_t *d_x, int32_t *d_y, int32_t *d_count,
+                          void *stream)
+{
+    AXT_REQUIRE(d_yolo && h_tile_yx && d_conf && d_x && d_y && d_count, "null argument");
+    AXT_REQUIRE(n_tiles >= 1 && n_tiles <= 28, "n_tiles %d: this kernel keeps a frame's candidates in LDS (max 28 tiles)",
+                n_tiles);
+    AXT_REQUIRE(cap >= n_tiles * AXT_CELLS, "cap %d < n_tiles*144 = %d", cap, n_tiles * AXT_CELLS);
+    AXT_REQUIRE(min_dist >= 0 && min_dist < 32768, "min_dist out of range");
+    if (n_frames <= 0) return AXT_OK;
+    TileOrigins tiles;
+    tiles.n = n_tiles;
+    for (int k = 0; k < n_tiles; ++k) {
+        tiles.yx[2 * k] = (short)h_tile_yx[2 * k];
+        tiles.yx[2 * k + 1] = (short)h_tile_yx[2 * k + 1];
+    }
+    const size_t lds = (size_t)n_tiles * AXT_CELLS * 7 * 4;
+    static bool attr = false;
+    if (!attr) {
+        AXT_CHECK_HIP(hipFuncSetAttribute((const void *)decode_stitch_nms_kernel,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 28 * AXT_CELLS * 7 * 4));
+        attr = true;
+    }
+    hipLaunchKernelGGL(decode_stitch_nms_kernel, dim3(n_frames), dim3(256), lds, (hipStream_t)stream, d_yolo, n_tiles,
+                       tiles, conf_thr, min_dist * min_dist, cap, d_conf, d_x, d_y, d_count);
+    AXT_LAUNCH_CHECK();
+    return AXT_OK;
+}
+
+}  // extern "C"

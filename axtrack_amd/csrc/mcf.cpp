@@ -1,0 +1,210 @@
+// Global data association: exact min-cost flow on the unit-capacity tracking network (host C++).
+//
+// Replaces libmot.data_association.MinCostFlowTracker.compute_trajectories() as driven by the reference at
+// axtrack/AxonDetections.py:663-690 (libmot itself is absent from the reference tree; formulation restated from
+// Zhang/Li/Nevatia CVPR'08 -- DESIGN.md "Unpinned third-party semantics").
+//
+// Network: source S, sink T, per detection k an observation arc u_k -> v_k (cost obs[k]), an entry arc S -> u_k,
+// an exit arc v_k -> T, and transition arcs v_a -> u_b (CSR by a). All capacities are 1, all costs integers.
+// The number of unit flows F in [min_flow, max_flow] with minimum total cost is wanted. The cost is convex
+// in F, so successive shortest augmenting paths stop exactly at that optimum:
+//   push while F < min_flow, or while F < max_flow and the next path has negative cost.
+//
+// Shortest paths: the network is a DAG in frame order, so the first potentials come from one DP sweep;
+// afterwards Dijkstra on reduced costs (Johnson potentials), stopped as soon as T is settled.
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <queue>
+#include <vector>
+
+#include "../../include/axtrack_hip.h"
+
+void axt_set_error(const char *fmt, ...);
+
+namespace {
+
+constexpr int64_t INF = INT64_MAX / 4;
+constexpr int32_t NONE = -2, TERMINAL = -1;   // pred: TERMINAL = fed by S; succ: TERMINAL = drains to T
+
+struct Solver {
+    int n;
+    const int64_t *obs, *entry, *exitc, *row_ptr, *cost;
+    const int32_t *col;
+    std::vector<int32_t> pred, succ;      // arc index of the flow-carrying in/out transition, TERMINAL or NONE
+    std::vector<int32_t> pred_tail;       // tail detection of pred[k] when pred[k] >= 0
+    std::vector<int64_t> pi, dist;
+    std::vector<int32_t> par;             // parent node on the shortest-path tree
+    std::vector<int32_t> par_arc;         // transition arc index used (or -1)
+    std::vector<int32_t> touched;
+    int S, T;
+
+    inline int U(int k) const { return 2 * k; }
+    inline int V(int k) const { return 2 * k + 1; }
+
+    void init_potentials()
+    {
+        pi.assign(2 * n + 2, INF);
+        pi[S] = 0;
+        for (int k = 0; k < n; ++k) pi[U(k)] = entry[k];
+        int64_t dT = INF;
+        for (int k = 0; k < n; ++k) {
+            const int64_t dv = pi[U(k)] + obs[k];
+            pi[V(k)] = dv;
+            for (int64_t e = row_ptr[k]; e < row_ptr[k + 1]; ++e) {
+                const int b = col[e];
+                if (dv + cost[e] < pi[U(b)]) pi[U(b)] = dv + cost[e];
+            }
+            if (dv + exitc[k] < dT) dT = dv + exitc[k];
+        }
+        pi[T] = dT;
+    }
+
+    // returns true if T was reached; dist/par filled for settled nodes
+    bool dijkstra()
+    {
+        typedef std::pair<int64_t, int32_t> Item;
+        std::priority_queue<Item, std::vector<Item>, std::greater<Item>> pq;
+        for (int32_t x : touched) dist[x] = INF;
+        touched.clear();
+        auto relax = [&](int from, int to, int64_t c, int64_t d, int32_t arc) {
+            const int64_t nd = d + c + pi[from] - pi[to];
+            if (nd < dist[to]) {
+                if (dist[to] == INF) touched.push_back(to);
+                dist[to] = nd;
+                par[to] = from;
+                par_arc[to] = arc;
+                pq.push(Item(nd, to));
+            }
+        };
+        dist[S] = 0;
+        touched.push_back(S);
+        for (int k = 0; k < n; ++k)
+            if (pred[k] != TERMINAL) relax(S, U(k), entry[k], 0, -1);
+        while (!pq.empty()) {
+            const Item it = pq.top();
+            pq.pop();
+            const int x = it.second;
+            const int64_t d = it.first;
+            if (d > dist[x]) continue;
+            if (x == T) return true;
+            const int k = x >> 1;
+            if ((x & 1) == 0) {   // u_k
+                if (pred[k] == NONE) relax(x, V(k), obs[k], d, -1);
+                else if (pred[k] >= 0) {
+                    const int32_t e = pred[k];
+                    relax(x, V(pred_tail[k]), -cost[e], d, e);
+                }
+            } else {              // v_k
+                if (succ[k] != TERMINAL) relax(x, T, exitc[k], d, -1);
+                const int32_t busy = succ[k];
+                for (int64_t e = row_ptr[k]; e < row_ptr[k + 1]; ++e)
+                    if ((int32_t)e != busy) relax(x, U(col[e]), cost[e], d, (int32_t)e);
+                if (pred[k] != NONE) relax(x, U(k), -obs[k], d, -1);
+            }
+        }
+        return false;
+    }
+
+    void augment()
+    {
+        // collect the path T <- ... <- S, then apply removals before additions
+        std::vector<std::pair<int32_t, int32_t>> steps;   // (from, to)
+        std::vector<int32_t> arcs;
+        for (int x = T; x != S; x = par[x]) {
+            steps.push_back(std::make_pair(par[x], x));
+            arcs.push_back(par_arc[x]);
+        }
+        for (size_t i = 0; i < steps.size(); ++i) {       // removals: backward transition arcs u_b -> v_a
+            const int from = steps[i].first, to = steps[i].second;
+            if (from != S && to != T && (from & 1) == 0 && (to & 1) == 1 && (from >> 1) != (to >> 1)) {
+                succ[to >> 1] = NONE;
+                pred[from >> 1] = NONE;
+            }
+        }
+        for (size_t i = 0; i < steps.size(); ++i) {       // additions
+            const int from = steps[i].first, to = steps[i].second;
+            if (from == S) pred[to >> 1] = TERMINAL;
+            else if (to == T) succ[from >> 1] = TERMINAL;
+            else if ((from & 1) == 1 && (to & 1) == 0 && (from >> 1) != (to >> 1)) {
+                succ[from >> 1] = arcs[i];
+                pred[to >> 1] = arcs[i];
+                pred_tail[to >> 1] = from >> 1;
+            }
+        }
+    }
+};
+
+}  // namespace
+
+extern "C" int axt_mcf_solve(int n_det, const int64_t *h_obs, const int64_t *h_entry, const int64_t *h_exit,
+                             const int64_t *h_row_ptr, const int32_t *h_col, const int64_t *h_cost, int min_flow,
+                             int max_flow, int32_t *h_next, int32_t *h_track, int *n_tracks, int64_t *total_cost)
+{
+    if (n_det < 0 || !h_row_ptr || !n_tracks || !total_cost || (n_det > 0 && (!h_obs || !h_entry || !h_exit || !h_next || !h_track))) {
+        axt_set_error("axt_mcf_solve: null or negative argument");
+        return AXT_EINVAL;
+    }
+    if (min_flow < 0 || max_flow < min_flow) {
+        axt_set_error("axt_mcf_solve: need 0 <= min_flow <= max_flow (got %d, %d)", min_flow, max_flow);
+        return AXT_EINVAL;
+    }
+    for (int k = 0; k < n_det; ++k)
+        for (int64_t e = h_row_ptr[k]; e < h_row_ptr[k + 1]; ++e)
+            if (h_col[e] <= k || h_col[e] >= n_det) {
+                axt_set_error("axt_mcf_solve: arc %lld of detection %d does not point forward in time", (long long)e, k);
+                return AXT_EINVAL;
+            }
+    *n_tracks = 0;
+    *total_cost = 0;
+    Solver s;
+    s.n = n_det;
+    s.obs = h_obs; s.entry = h_entry; s.exitc = h_exit; s.row_ptr = h_row_ptr; s.cost = h_cost; s.col = h_col;
+    s.S = 2 * n_det; s.T = 2 * n_det + 1;
+    s.pred.assign(n_det, NONE);
+    s.succ.assign(n_det, NONE);
+    s.pred_tail.assign(n_det, -1);
+    s.dist.assign(2 * n_det + 2, INF);
+    s.par.assign(2 * n_det + 2, -1);
+    s.par_arc.assign(2 * n_det + 2, -1);
+    int F = 0;
+    int64_t total = 0;
+    if (n_det > 0) {
+        s.init_potentials();
+        while (F < max_flow) {
+            if (!s.dijkstra()) break;
+            const int64_t dT = s.dist[s.T];
+            const int64_t path_cost = dT + s.pi[s.T] - s.pi[s.S];
+            if (F >= min_flow && path_cost >= 0) break;
+            // Johnson update pi'[x] = pi[x] + min(dist[x], dT) keeps every residual reduced cost >= 0. Adding
+            // the same constant to all potentials changes no reduced cost, so instead of +dT on the (many)
+            // nodes the search never touched, the touched ones get min(dist, dT) - dT <= 0.
+            for (int32_t x : s.touched) s.pi[x] += (s.dist[x] < dT ? s.dist[x] : dT) - dT;
+            s.augment();
+            total += path_cost;
+            ++F;
+        }
+    }
+    if (F < min_flow) {
+        for (int k = 0; k < n_det; ++k) { h_next[k] = -1; h_track[k] = -1; }
+        return AXT_INFEASIBLE;
+    }
+    int id = 0;
+    for (int k = 0; k < n_det; ++k) { h_next[k] = -1; h_track[k] = -1; }
+    for (int k = 0; k < n_det; ++k) {
+        if (s.pred[k] != TERMINAL) continue;
+        int x = k;
+        for (;;) {
+            h_track[x] = id;
+            const int32_t e = s.succ[x];
+            if (e < 0) break;
+            h_next[x] = h_col[e];
+            x = h_col[e];
+        }
+        ++id;
+    }
+    *n_tracks = id;
+    *total_cost = total;
+    return AXT_OK;
+}

@@ -1,0 +1,309 @@
+"""AxonDetections: the reference's orchestration class (axtrack/AxonDetections.py) re-hosted on
+the HIP hot path. Same public surface on the inference path -- detect_dataset(), assign_ids(),
+get_frame_dets(), IDed_dets_all, _detections, dir, name, len() -- but a timelapse is processed as
+whole-array GPU passes instead of a Python loop over frames and DataFrames:
+
+    detect_dataset : tile occupancy -> CNN forward for all (frame, tile) -> decode+stitch+NMS
+    assign_ids     : observation costs + admissible-arc list on the GPU -> min-cost-flow solve
+                     -> trajectories -> IDed_dets_all
+
+pandas objects are only materialised at the API boundary (lazily for the per-frame tables).
+"""
+import os
+import pickle
+
+import numpy as np
+import pandas as pd
+import torch
+
+from . import hotpath as hp
+
+
+def transition_cost_table(P, max_px=hp.MAX_PX_ASSOC_DIST):
+    """transition_model (mincostflow_models.py:67-119) tabulated for every integer path length
+    D = 0..max_px and gap = 1..MCF_MAX_NUM_MISSES+1, numpy f64 exactly as the reference computes
+    it (vis_sim_weight must be 0: the visual term is a "next" row). Returns (cost f64
+    [gaps, max_px+1], dmax i32 [gaps]) with dmax = largest D whose cost < MCF_EDGE_COST_THR."""
+    w = P['MCF_VIS_SIM_WEIGHT']
+    if w != 0:
+        raise NotImplementedError('MCF_VIS_SIM_WEIGHT > 0 (feature_model / compareHist) is not part of this build')
+    gaps = P['MCF_MAX_NUM_MISSES'] + 1
+    D = np.arange(0, max_px + 1)
+    table = np.empty((gaps, max_px + 1))
+    dmax = np.zeros(gaps, np.int32)
+    for g in range(1, gaps + 1):
+        distances = ((D / max_px) - 1) * -1
+        with np.errstate(divide='ignore'):
+            costs = -np.log((1 - w) * distances * (P['MCF_MISS_RATE'] ** (g - 1)) + w * 0.0 + 1e-6)
+        costs[distances == 0] = np.inf
+        table[g - 1] = costs
+        ok = np.nonzero(costs[1:] < P['MCF_EDGE_COST_THR'])[0]
+        dmax[g - 1] = ok.max() + 1 if len(ok) else 0
+    return table, dmax
+
+
+class AxonDetections(object):
+    def __init__(self, model, dataset, parameters, directory, timepoint_subset=None):
+        self.model = model
+        self.dataset = dataset
+        self.name = dataset.name
+        self.dir = directory
+        if self.dir:
+            os.makedirs(self.dir, exist_ok=True)
+        if timepoint_subset is not None:
+            raise NotImplementedError('timepoint_subset is a training/evaluation feature (out of scope)')
+        self.timepoint_subset = range(self.dataset.sizet)
+        self.P = dict(parameters)
+        self.device = dataset.device
+        self.Sx, self.Sy, self.tilesize = parameters['SX'], parameters['SY'], parameters['TILESIZE']
+        if (self.Sx, self.Sy, self.tilesize) != (hp.S, hp.S, hp.TILE):
+            raise ValueError('the HIP detector is specialised for TILESIZE=512, SX=SY=12')
+        self.nms_min_dist = parameters.get('NON_MAX_SUPRESSION_DIST')
+        self.conf_thr = parameters['BBOX_THRESHOLD']
+        self.all_conf_thrs = np.sort(np.append(np.arange(0.55, 1, .04), self.conf_thr)).round(2)
+        self.max_px_assoc_dist = hp.MAX_PX_ASSOC_DIST
+        self.axon_box_size = hp.AXON_BOX_SIZE
+        self.labelled = False
+        self.conn8 = bool(parameters.get('ASTAR_8_CONNECTED', False))
+        self.reproduce_label_quirk = bool(parameters.get('REPRODUCE_FRAME_LABEL_QUIRK', True))
+        self._det_tables = None
+
+    def __len__(self):
+        return len(self.timepoint_subset)
+
+    # ------------------------------------------------------------------ caches (AxonDetections.py:141-176)
+    def _cache_fname(self, which):
+        return f'{self.dir}/{self.dataset.name}_{which}.pkl'
+
+    def from_cache(self, which):
+        with open(self._cache_fname(which), 'rb') as file:
+            return pickle.load(file)
+
+    def to_cache(self, which, dat):
+        with open(self._cache_fname(which), 'wb') as file:
+            pickle.dump(dat, file)
+
+    # ------------------------------------------------------------------ detection (AxonDetections.py:87-139)
+    def detect_dataset(self, cache=None):
+        if cache == 'from':
+            self._set_detections_from_tables(self.from_cache('_detections'))
+            return
+        frames = self.dataset.frames
+        self.tile_yx = hp.tile_occupancy(frames)
+        if not self.tile_yx:
+            raise ValueError('the timelapse is empty (no tile has a non-zero pixel)')
+        self._yolo = self.model.detect_frames(frames, self.tile_yx, 0, len(self))
+        thr = float(np.float32(self.all_conf_thrs.min()))
+        self.d_conf, self.d_x, self.d_y, self.d_count = hp.decode_stitch_nms(
+            self._yolo, self.tile_yx, thr, self.nms_min_dist)
+        self._det_tables = None
+        self._host = None
+        if cache == 'to':
+            self.to_cache('_detections', self._detections)
+
+    def _host_dets(self):
+        """(count i32 [F], conf f32 [F,cap], x, y) on the host, fetched once."""
+        if getattr(self, '_host', None) is None:
+            self._host = (self.d_count.cpu().numpy(), self.d_conf.cpu().numpy(), self.d_x.cpu().numpy(),
+                          self.d_y.cpu().numpy())
+        return self._host
+
+    def _set_detections_from_tables(self, tables):
+        F = len(tables)
+        cap = max([len(t) for t in tables] + [1])
+        conf = np.zeros((F, cap), np.float32); x = np.zeros((F, cap), np.int32); y = np.zeros((F, cap), np.int32)
+        cnt = np.zeros(F, np.int32)
+        for f, t in enumerate(tables):
+            n = len(t)
+            cnt[f] = n
+            conf[f, :n] = t.conf.to_numpy(dtype=np.float32)
+            x[f, :n] = t.anchor_x.to_numpy(dtype=np.int32)
+            y[f, :n] = t.anchor_y.to_numpy(dtype=np.int32)
+        dev = self.device
+        self.d_conf, self.d_x, self.d_y, self.d_count = (torch.from_numpy(a).to(dev) for a in (conf, x, y, cnt))
+        self._host, self._det_tables = (cnt, conf, x, y), list(tables)
+
+    @property
+    def _detections(self):
+        """list of per-frame DataFrames [conf Float32, anchor_x Int64, anchor_y Int64], index
+        Axon_000.. in descending confidence (AxonDetections.py:235,261,276-277)."""
+        if self._det_tables is None:
+            cnt, conf, x, y = self._host_dets()
+            tabs = []
+            for f in range(len(cnt)):
+                n = int(cnt[f])
+                tabs.append(pd.DataFrame({'conf': pd.array(conf[f, :n], dtype='Float32'),
+                                          'anchor_x': pd.array(x[f, :n].astype(np.int64), dtype='Int64'),
+                                          'anchor_y': pd.array(y[f, :n].astype(np.int64), dtype='Int64')},
+                                         index=[f'Axon_{i:0>3}' for i in range(n)]))
+            self._det_tables = tabs
+        return self._det_tables
+
+    # ------------------------------------------------------------------ access (AxonDetections.py:280-353)
+    def get_frame_dets(self, which_dets, t, libmot=False, unstitched=False):
+        if unstitched:
+            raise NotImplementedError('unstitched tile tables are not kept by the HIP path')
+        if t is None:
+            all_dets = [self.get_frame_dets(which_dets, t, libmot) for t in range(len(self))]
+            return pd.concat(all_dets, axis=not libmot)
+        if which_dets == 'all':
+            det = self._detections[t]
+        elif which_dets == 'confident':
+            det = self._detections[t][self._detections[t].conf > self.conf_thr]
+        elif which_dets == 'IDed':
+            assert getattr(self, '_IDed_detections', None), "Run .assign_IDs() first!"
+            det = self._IDed_detections[t]
+        else:
+            raise NotImplementedError(f"which_dets={which_dets!r} needs labels (out of scope)")
+        if libmot:
+            return self.det2libmot_det(det, t)
+        return det.copy()
+
+    def det2libmot_det(self, detection, t):
+        """AxonDetections.py:754-784"""
+        conf, x, y = detection.values.T
+        half = self.axon_box_size // 2
+        frame_id = np.full(conf.shape, t)
+        boxs = np.full(conf.shape, self.axon_box_size)
+        axon_id = np.array([int(idx[-3:]) for idx in detection.index])
+        det_libmot = np.stack([frame_id, axon_id, x - half, y - half, boxs, boxs, conf]).T
+        cols = ['FrameId', 'Id', 'X', 'Y', 'Width', 'Height', 'conf']
+        return pd.DataFrame(det_libmot, columns=cols).set_index(['FrameId', 'Id'])
+
+    # ------------------------------------------------------------------ association (AxonDetections.py:505-524)
+    def assign_ids(self, astar_paths_cache=None, assigedIDs_cache=None):
+        if assigedIDs_cache == 'from':
+            self._IDed_detections = self.from_cache('_IDed_detections')
+        else:
+            self._IDed_detections = self._assign_IDs_to_detections()
+            if assigedIDs_cache == 'to' and self._IDed_detections is not None:
+                self.to_cache('_IDed_detections', self._IDed_detections)
+        self.IDed_dets_all = self._agg_all_IDed_dets() if self._IDed_detections is not None else None
+
+    def astar_dists(self):
+        """_get_astar_path_distances(_compute_detections_astar_paths()) (AxonDetections.py:526-585,717-752):
+        dict '{name}_t:{t:03}-t:{t_bef:03}' -> int array [N_t_bef, N_t], computed on the GPU per pair."""
+        cnt = self._host_dets()[0]
+        mask = self._mask_dev()
+        out = {}
+        for t in range(len(self)):
+            for t_bef in range(t - 1, t - (self.P['MCF_MAX_NUM_MISSES'] + 2), -1):
+                if t_bef < 0:
+                    continue
+                na, nb = int(cnt[t_bef]), int(cnt[t])
+                lbl = f'{self.dataset.name}_t:{t:0>3}-t:{t_bef:0>3}'
+                if na == 0:
+                    out[lbl] = np.array([])
+                    continue
+                D = hp.path_cost(self.d_x[t_bef, :na], self.d_y[t_bef, :na], self.d_x[t, :nb], self.d_y[t, :nb],
+                                 self.dataset.sizey, self.dataset.sizex, mask, self.max_px_assoc_dist, self.conn8)
+                out[lbl] = D.cpu().numpy()
+        return out
+
+    def _mask_dev(self):
+        m = self.dataset.mask2d
+        if m is None:
+            return None
+        if getattr(self, '_mask_t', None) is None:
+            self._mask_t = torch.from_numpy(np.ascontiguousarray(m, np.uint8)).to(self.device)
+        return self._mask_t
+
+    def _assign_IDs_to_detections(self):
+        """AxonDetections.py:631-715 with the tracker replaced by axt_build_arcs + axt_mcf_solve."""
+        P = self.P
+        if self.dataset.mask2d is not None:
+            raise NotImplementedError('masked timelapses (A* on a non-trivial mask) are not built yet')
+        table, dmax = transition_cost_table(P, self.max_px_assoc_dist)
+        units = np.where(np.isfinite(table), np.rint(table * 1e6), 0).astype(np.int64)
+        obs = hp.obs_costs(self.d_conf, self.d_count, P['MCF_CONF_CAPPING_METHOD'], P['MCF_MAX_CONF_COST'])
+        row_ptr, col, length, gap, cost = hp.build_arcs(self.d_x, self.d_y, self.d_count, self.dataset.sizey,
+                                                        self.dataset.sizex, dmax, units, None,
+                                                        self.max_px_assoc_dist, self.conn8)
+        cnt, conf, x, y = self._host_dets()
+        offs = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+        n_det = int(offs[-1])
+        obs_h = obs.cpu().numpy()
+        valid = np.arange(conf.shape[1])[None, :] < cnt[:, None]
+        obs_flat = obs_h[valid]
+        k = np.arange(n_det, dtype=np.int64)
+        obs_int = _arc_cost_int_vec(obs_flat, 2, k, 0)
+        ee = float(P['MCF_ENTRY_EXIT_COST'])
+        entry_int = _arc_cost_int_vec(np.full(n_det, ee), 0, k, 0)
+        exit_int = _arc_cost_int_vec(np.full(n_det, ee), 1, k, 0)
+        res = hp.mcf_solve(obs_int, entry_int, exit_int, row_ptr[:n_det + 1].cpu().numpy(), col.cpu().numpy(),
+                           cost.cpu().numpy(), P['MCF_MIN_FLOW'], P['MCF_MAX_FLOW'])
+        if res is None:
+            print('Could not solve the graph for identity association; -> no IDed detections. Try narrowing '
+                  'expected identities by updating parameters[`MCF_MIN_FLOW`, `MCF_MAX_FLOW`]. '
+                  f"Currently: {P['MCF_MIN_FLOW']} to {P['MCF_MAX_FLOW']}.")
+            return None
+        nxt, track, n_tracks, total = res
+        self.mcf_total_cost, self.n_ids = total, n_tracks
+        self._track_flat, self._offs = track, offs
+        # per-frame tables, rows sorted by ID (libmot_det2det, AxonDetections.py:786-823)
+        frame_of = np.repeat(np.arange(len(cnt)), cnt)
+        idx_in = k - offs[frame_of]
+        sel = track >= 0
+        tabs = []
+        order = np.lexsort((track[sel], frame_of[sel]))
+        f_s, id_s, i_s = frame_of[sel][order], track[sel][order], idx_in[sel][order]
+        bounds = np.searchsorted(f_s, np.arange(len(cnt) + 1))
+        for f in range(len(cnt)):
+            lo, hi = bounds[f], bounds[f + 1]
+            if lo == hi:
+                tabs.append(pd.DataFrame([]))
+                continue
+            ii = i_s[lo:hi]
+            tabs.append(pd.DataFrame({'conf': pd.array(conf[f, ii], dtype='Float32'),
+                                      'anchor_x': pd.array(x[f, ii].astype(np.int64), dtype='Int64'),
+                                      'anchor_y': pd.array(y[f, ii].astype(np.int64), dtype='Int64')},
+                                     index=[f'Axon_{i:0>3}' for i in id_s[lo:hi]]))
+        return tabs
+
+    def ided_arrays(self):
+        """(frame i32, id i32, conf f32, x i32, y i32) of every IDed detection, frame-major."""
+        cnt, conf, x, y = self._host_dets()
+        frame_of = np.repeat(np.arange(len(cnt)), cnt)
+        k = np.arange(len(frame_of))
+        idx_in = k - self._offs[frame_of]
+        sel = self._track_flat >= 0
+        return (frame_of[sel], self._track_flat[sel], conf[frame_of[sel], idx_in[sel]], x[frame_of[sel], idx_in[sel]],
+                y[frame_of[sel], idx_in[sel]])
+
+    def _agg_all_IDed_dets(self):
+        """AxonDetections.py:825-842, including (by default) its frame-label quirk: labels are
+        column_position//3, so frames after one without IDed detections are labelled one too low."""
+        F = len(self)
+        frame, tid, conf, x, y = self.ided_arrays()
+        ids = np.unique(tid)
+        row = np.searchsorted(ids, tid)
+        present = np.zeros(F, bool)
+        present[frame] = True
+        if self.reproduce_label_quirk:
+            slot_of_frame = np.cumsum(present) - 1          # frames without IDs vanish from the concat (:831)
+        else:
+            slot_of_frame = np.arange(F)
+        vals = np.full((len(ids), 3 * F), np.nan)
+        s = slot_of_frame[frame]
+        vals[row, 3 * s + 0] = x
+        vals[row, 3 * s + 1] = y
+        vals[row, 3 * s + 2] = conf.astype(np.float64)
+        cols = pd.MultiIndex.from_product([range(F), ['anchor_x', 'anchor_y', 'conf']], names=('frameID', 'detInfo'))
+        df = pd.DataFrame(vals, index=[f'Axon_{i:0>3}' for i in ids], columns=cols)
+        df.index.rename('axonID', inplace=True)
+        return df
+
+
+def _splitmix64(x):
+    x = x + np.uint64(0x9E3779B97F4A7C15)
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return x ^ (x >> np.uint64(31))
+
+
+def _arc_cost_int_vec(cost, kind, a, b):
+    """Vectorised axt_arc_cost_int (include/axtrack_hip.h)."""
+    with np.errstate(over='ignore'):
+        key = (np.uint64(kind) << np.uint64(60)) ^ (np.asarray(a, np.uint64) << np.uint64(30)) ^ np.asarray(b, np.uint64)
+        pert = (_splitmix64(key) & np.uint64(0xFFFF)).astype(np.int64)
+    return np.rint(np.asarray(cost, np.float64) * 1e6).astype(np.int64) * 65536 + pert

@@ -1,0 +1,222 @@
+"""Thin Python wrappers over the C ABI (include/axtrack_hip.h): torch tensors own the device
+memory and the stream, the HIP library does the work. Each wrapper names the reference call
+it stands in for."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import synth
+
+TILE, S, CELLS = 512, 12, 144
+CONF_FLOOR = float(np.float32(0.55))   # all_conf_thrs.min() as f32 (AxonDetections.py:76,122)
+MAX_PX_ASSOC_DIST = 500                # AxonDetections.py:77
+AXON_BOX_SIZE = 70                     # AxonDetections.py:78
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise _lib.AxtError('axtrack_amd needs a ROCm GPU (MI355X, gfx950); there is no CPU path')
+
+
+def state_dict_tensor_order():
+    """Key order axt_detector_create expects (include/axtrack_hip.h)."""
+    keys = []
+    for name in synth.conv_block_names():
+        for k in ('conv.weight', 'conv.bias', 'batchnorm.weight', 'batchnorm.bias',
+                  'batchnorm.running_mean', 'batchnorm.running_var'):
+            keys.append(f'ConvNet.{name}.{k}')
+    for idx in (1, 3, 5):
+        keys += [f'fcs.{idx}.weight', f'fcs.{idx}.bias']
+    return keys
+
+
+class Detector:
+    """Device-resident YOLO_AXTrack (model.py:20-125) in eval mode; `detect_axons` keeps the
+    reference's name and tensor contract (model.py:119-125)."""
+
+    def __init__(self, state_dict, max_batch=256, device='cuda:0'):
+        _require_gpu()
+        self.device = torch.device(device)
+        self.max_batch = int(max_batch)
+        lib = _lib.load()
+        keep = []
+        for k in state_dict_tensor_order():
+            if k not in state_dict:
+                raise KeyError(f'state_dict lacks {k}')
+            v = state_dict[k]
+            v = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            keep.append(np.ascontiguousarray(v, np.float32))
+        arr = (ctypes.c_void_p * len(keep))(*[a.ctypes.data for a in keep])
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.axt_detector_create(arr, len(keep), self.max_batch, ctypes.byref(handle)),
+                       'axt_detector_create')
+        self._h = handle
+        self._lib = lib
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h:
+            self._lib.axt_detector_destroy(h)
+
+    @property
+    def device_bytes(self):
+        return int(self._lib.axt_detector_device_bytes(self._h))
+
+    def eval(self):
+        return self
+
+    def train(self, mode=True):
+        return self
+
+    def to(self, device):
+        if torch.device(device) != self.device:
+            raise _lib.AxtError('the detector is bound to the device it was created on')
+        return self
+
+    def detect_axons(self, X):
+        """X f32 [B,5,512,512] on the GPU -> [B,12,12,3] (model.py:119-125)."""
+        if X.dim() != 4 or tuple(X.shape[1:]) != (5, TILE, TILE):
+            raise ValueError(f'expected [B,5,{TILE},{TILE}], got {tuple(X.shape)}')
+        X = X.to(self.device, torch.float32).contiguous()
+        out = torch.empty((X.shape[0], S, S, 3), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.axt_cnn_forward(self._h, X.data_ptr(), X.shape[0], out.data_ptr(), _stream()),
+                       'axt_cnn_forward')
+        return out
+
+    def detect_frames(self, frames, tile_yx, t0=0, n_frames=None):
+        """frames f32 [T_all,H,W] on the GPU -> YOLO grids [n_frames, n_tiles, 12,12,3] for detection
+        frames t0..t0+n_frames-1 (get_frametiles_stack + detect_axons, AxonDetections.py:115-118)."""
+        T_all, H, W = frames.shape
+        if n_frames is None:
+            n_frames = T_all - 4 - t0
+        tile_yx = np.ascontiguousarray(tile_yx, np.int32).reshape(-1, 2)
+        out = torch.empty((n_frames, len(tile_yx), S, S, 3), dtype=torch.float32, device=self.device)
+        assert frames.is_contiguous() and frames.dtype == torch.float32 and frames.device == self.device
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.axt_cnn_forward_frames(self._h, frames.data_ptr(), T_all, H, W, t0, n_frames,
+                                                        tile_yx.ctypes.data, len(tile_yx), out.data_ptr(), _stream()),
+                       'axt_cnn_forward_frames')
+        return out
+
+
+def tile_occupancy(frames):
+    """Kept tiles, row-major list of (tile_row, tile_col) (Timelapse.py:551-558)."""
+    T_all, H, W = frames.shape
+    nty, ntx = -(-H // TILE), -(-W // TILE)
+    occ = torch.empty(nty * ntx, dtype=torch.uint8, device=frames.device)
+    lib = _lib.load()
+    with torch.cuda.device(frames.device):
+        _lib.check(lib.axt_tile_occupancy(frames.data_ptr(), T_all, H, W, occ.data_ptr(), _stream()),
+                   'axt_tile_occupancy')
+    occ = occ.cpu().numpy().reshape(nty, ntx)
+    return [tuple(int(v) for v in ix) for ix in np.argwhere(occ)]
+
+
+def decode_stitch_nms(yolo, tile_yx, conf_thr=CONF_FLOOR, min_dist=23, cap=None):
+    """_yolo_Y2pandas_det + stitch_tiles + _non_max_supression per frame
+    (AxonDetections.py:122-128). yolo [n_frames, n_tiles, 12,12,3] on the GPU.
+    Returns device tensors conf f32 [F,cap], x i32, y i32, count i32 [F]."""
+    n_frames, n_tiles = yolo.shape[0], yolo.shape[1]
+    tile_yx = np.ascontiguousarray(tile_yx, np.int32).reshape(-1, 2)
+    assert len(tile_yx) == n_tiles and yolo.is_contiguous()
+    cap = cap or n_tiles * CELLS
+    dev = yolo.device
+    conf = torch.zeros((n_frames, cap), dtype=torch.float32, device=dev)
+    x = torch.zeros((n_frames, cap), dtype=torch.int32, device=dev)
+    y = torch.zeros((n_frames, cap), dtype=torch.int32, device=dev)
+    count = torch.zeros((n_frames,), dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        _lib.check(lib.axt_decode_stitch_nms(yolo.data_ptr(), n_frames, n_tiles, tile_yx.ctypes.data,
+                                             ctypes.c_float(conf_thr), int(min_dist), cap, conf.data_ptr(),
+                                             x.data_ptr(), y.data_ptr(), count.data_ptr(), _stream()),
+                   'axt_decode_stitch_nms')
+    return conf, x, y, count
+
+
+def obs_costs(conf, count, method='scale_to_max', max_conf_cost=4.6):
+    """conf capping + observation_model (AxonDetections.py:655-659, mincostflow_models.py:6-27)."""
+    n_frames, cap = conf.shape
+    cost = torch.zeros((n_frames, cap), dtype=torch.float64, device=conf.device)
+    m = {'scale_to_max': 0, 'ceil': 1}[method]
+    lib = _lib.load()
+    with torch.cuda.device(conf.device):
+        _lib.check(lib.axt_obs_costs(conf.data_ptr(), count.data_ptr(), n_frames, cap, m, float(max_conf_cost),
+                                     cost.data_ptr(), _stream()), 'axt_obs_costs')
+    return cost
+
+
+def path_cost(xa, ya, xb, yb, H, W, mask=None, max_dist=MAX_PX_ASSOC_DIST, conn8=False):
+    """A* path-length matrix of one frame pair (AxonDetections.py:526-629,717-752)."""
+    na, nb = xa.numel(), xb.numel()
+    D = torch.empty((na, nb), dtype=torch.int32, device=xa.device)
+    lib = _lib.load()
+    with torch.cuda.device(xa.device):
+        _lib.check(lib.axt_path_cost(xa.data_ptr(), ya.data_ptr(), na, xb.data_ptr(), yb.data_ptr(), nb,
+                                     _lib.dptr(mask), H, W, int(max_dist), int(bool(conn8)), D.data_ptr(),
+                                     _stream()), 'axt_path_cost')
+    return D
+
+
+def build_arcs(x, y, count, H, W, dmax, cost_units=None, mask=None, max_dist=MAX_PX_ASSOC_DIST, conn8=False):
+    """Admissible transition arcs of the whole timelapse, CSR by tail detection (global numbering).
+    cost_units: optional int64 [max_gap, max_dist+1] = round(transition cost * 1e6) per (gap, D).
+    Returns device tensors (row_ptr i64 [n_frames*cap+1], col i32, length i16, gap u8, cost i64|None)."""
+    n_frames, cap = x.shape
+    max_gap = len(dmax)
+    dev = x.device
+    h_dmax = np.ascontiguousarray(dmax, np.int32)
+    row_ptr = torch.empty((n_frames * cap + 1,), dtype=torch.int64, device=dev)
+    work = torch.empty((n_frames * cap * max_gap + n_frames + 1 + max_gap,), dtype=torch.int32, device=dev)
+    n_arcs = ctypes.c_int64(0)
+    lib = _lib.load()
+    args = (x.data_ptr(), y.data_ptr(), count.data_ptr(), n_frames, cap, _lib.dptr(mask), H, W, int(max_dist),
+            int(bool(conn8)), max_gap, h_dmax.ctypes.data, row_ptr.data_ptr(), work.data_ptr())
+    with torch.cuda.device(dev):
+        _lib.check(lib.axt_build_arcs(*args, None, None, None, None, None, ctypes.byref(n_arcs), _stream()),
+                   'axt_build_arcs(count)')
+        n = max(int(n_arcs.value), 1)
+        col = torch.empty((n,), dtype=torch.int32, device=dev)
+        length = torch.empty((n,), dtype=torch.int16, device=dev)
+        gap = torch.empty((n,), dtype=torch.uint8, device=dev)
+        cost = cu = None
+        if cost_units is not None:
+            cu = torch.as_tensor(np.ascontiguousarray(cost_units, np.int64)).to(dev)
+            assert cu.shape == (max_gap, max_dist + 1)
+            cost = torch.empty((n,), dtype=torch.int64, device=dev)
+        _lib.check(lib.axt_build_arcs(*args, col.data_ptr(), length.data_ptr(), gap.data_ptr(), _lib.dptr(cu),
+                                      _lib.dptr(cost), ctypes.byref(n_arcs), _stream()), 'axt_build_arcs(fill)')
+    n = int(n_arcs.value)
+    return row_ptr, col[:n], length[:n], gap[:n], (cost[:n] if cost is not None else None)
+
+
+def arc_cost_int(cost, kind, a, b):
+    return int(_lib.load().axt_arc_cost_int(float(cost), int(kind), int(a), int(b)))
+
+
+def mcf_solve(obs_int, entry_int, exit_int, row_ptr, col, cost_int, min_flow, max_flow):
+    """MinCostFlowTracker.compute_trajectories (AxonDetections.py:690) on host arrays.
+    Returns (next i32 [n], track i32 [n], n_tracks, total_cost) or None when infeasible."""
+    n = len(obs_int)
+    arrs = [np.ascontiguousarray(a, np.int64) for a in (obs_int, entry_int, exit_int, row_ptr)]
+    col = np.ascontiguousarray(col, np.int32)
+    cost_int = np.ascontiguousarray(cost_int, np.int64)
+    nxt = np.empty(n, np.int32)
+    track = np.empty(n, np.int32)
+    n_tracks, total = ctypes.c_int(0), ctypes.c_int64(0)
+    lib = _lib.load()
+    rc = _lib.check(lib.axt_mcf_solve(n, arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data,
+                                      arrs[3].ctypes.data, col.ctypes.data, cost_int.ctypes.data, int(min_flow),
+                                      int(max_flow), nxt.ctypes.data, track.ctypes.data, ctypes.byref(n_tracks),
+                                      ctypes.byref(total)), 'axt_mcf_solve')
+    if rc == 1:
+        return None
+    return nxt, track, int(n_tracks.value), int(total.value)

@@ -1,0 +1,70 @@
+"""Input container of the hot path: the timelapse as ONE dense f32 tensor in HBM.
+
+Mirrors the attributes of the reference's Timelapse (axtrack/Timelapse.py) that the inference
+path reads -- name, sizet/sizey/sizex, tilesize, mask, len() -- but keeps only what the
+detector consumes: channel 0 of `X` (Timelapse.py:426-433; the two motion channels are all
+zeros for USE_MOTION_DATA='exclude', :366-367), context-padded: T_all = sizet + 2*context.
+"""
+import numpy as np
+import torch
+
+
+class Timelapse:
+    def __init__(self, frames, name='timelapse', mask=None, temporal_context=2, tilesize=512,
+                 device='cuda:0', pixelsize=None, dt=None, incubation_time=None):
+        """frames: preprocessed f32 [T_all,H,W] (numpy or torch); mask: bool [H,W] or None (all ones)."""
+        if temporal_context != 2:
+            raise ValueError('the deployed detector has 5 input channels: temporal_context must be 2')
+        f = torch.as_tensor(frames)
+        if f.dim() != 3:
+            raise ValueError(f'frames must be [T_all,H,W], got {tuple(f.shape)}')
+        if f.shape[0] < 2 * temporal_context + 1:
+            raise ValueError('need at least 5 frames (2 context frames either side of one detection frame)')
+        self.frames = f.to(device=device, dtype=torch.float32).contiguous()
+        self.name = name
+        self.temporal_context = temporal_context
+        self.tilesize = tilesize
+        self.sizet = self.frames.shape[0] - 2 * temporal_context
+        self.sizey, self.sizex = int(self.frames.shape[1]), int(self.frames.shape[2])
+        self.ytiles, self.xtiles = -(-self.sizey // tilesize), -(-self.sizex // tilesize)
+        if mask is not None:
+            mask = np.asarray(mask).astype(bool)
+            if mask.shape != (self.sizey, self.sizex):
+                raise ValueError('mask must be [H,W]')
+            if mask.all():
+                mask = None
+        self.mask2d = mask
+        self.pixelsize, self.dt, self.incubation_time = pixelsize, dt, incubation_time
+        self.timepoints = np.arange(temporal_context, temporal_context + self.sizet)
+
+    def __len__(self):
+        return self.sizet
+
+    @property
+    def device(self):
+        return self.frames.device
+
+
+def preprocess(imseq, mask=None, offset=121, clip=55, log_correct=True, scale=0.015176106):
+    """Dense preprocessing of a raw uint16 timelapse as Timelapse._read_tiff / _clip_image_values /
+    _log_adjust_image / _standardize do it (Timelapse.py:205-326): u16 -> f32 in [0,1], mask,
+    subtract offset/2^16 and clamp at 0, zero below clip/2^16, log2(1+x), divide by the train-set
+    std. `img_as_float32` and `adjust_log` are skimage functions that are absent here: their
+    arithmetic (x/65535, log2(1+x)) is restated from the published skimage 0.18 behaviour,
+    PARITY UNPINNED (a "next" row)."""
+    x = torch.as_tensor(np.asarray(imseq))
+    if x.dtype in (torch.uint16, torch.int32, torch.int16):
+        x = x.to(torch.float32) / 65535.0
+    else:
+        x = x.to(torch.float32)
+    if mask is not None:
+        x = x * torch.as_tensor(np.asarray(mask)).to(torch.float32)
+    if offset:
+        off = offset / 2 ** 16 if isinstance(offset, int) else offset
+        x = (x - off).clamp_(min=0)
+    if clip:
+        lo = clip / 2 ** 16 if isinstance(clip, int) else clip
+        x = torch.where(x < lo, torch.zeros_like(x), x)
+    if log_correct:
+        x = torch.log2(1 + x)
+    return x / scale

@@ -1,0 +1,171 @@
+/*
+ * axtrack_hip.h -- C ABI of libaxtrack_hip.so: AxTrack's detect + associate hot path on MI355X (gfx950).
+ *
+ * The reference (LoaloaF/axtrack) is pure Python; it has no FFI of its own. The seams this
+ * library replaces are the Python call sites listed per function below (paths relative to the
+ * reference repo). INTEGRATION.md shows the ctypes binding a maintainer of the reference adds.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes. Pointers prefixed d_ are DEVICE pointers (HIP),
+ *     h_ are HOST pointers. `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - Every function returns 0 on success, a negative AXT_E* code on error and never throws;
+ *     axt_last_error() returns a human-readable message for the calling thread.
+ *   - No hidden global state: all device state lives in an axt_detector handle or in
+ *     caller-provided buffers; calls are asynchronous on `stream` unless stated otherwise.
+ *   - Detections of a frame are three parallel arrays (conf f32, x i32, y i32) of capacity
+ *     `cap` per frame, sorted by descending confidence, plus a per-frame count.
+ */
+#ifndef AXTRACK_HIP_H
+#define AXTRACK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AXT_OK 0
+#define AXT_EINVAL (-22)   /* bad argument (shape, null pointer, capacity)          */
+#define AXT_ENOMEM (-12)   /* device or host allocation failed                       */
+#define AXT_EHIP (-5)      /* a HIP runtime call failed, see axt_last_error()        */
+#define AXT_INFEASIBLE 1   /* axt_mcf_solve: fewer than min_flow unit flows exist    */
+
+#define AXT_TILE 512       /* TILESIZE (deployed_model/params.txt:33)                */
+#define AXT_S 12           /* SX = SY  (deployed_model/params.txt:34-35)             */
+#define AXT_CELLS (AXT_S * AXT_S)
+#define AXT_YOLO_FLOATS (AXT_CELLS * 3)
+#define AXT_IN_CH 5        /* 1 * (2*TEMPORAL_CONTEXT+1), core_functionality.py:66   */
+#define AXT_N_WEIGHT_TENSORS 54   /* 8 conv blocks x 6 + 3 linear x 2                */
+
+const char *axt_last_error(void);
+int axt_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Detector: replaces YOLO_AXTrack (axtrack/machinelearning/model.py:20-125) in eval mode.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct axt_detector axt_detector;
+
+/* Builds the device-resident detector from the tensors of the reference's state_dict
+ * (checkpoint layout: utils.py:258-272; key set: model.py:85-117).
+ * h_tensors[54], host f32, in this order:
+ *   for blk in ConvBlock_{0,1,2,4,5,7,8,10}:
+ *     conv.weight[Co,Ci,3,3], conv.bias[Co], batchnorm.weight[Co], batchnorm.bias[Co],
+ *     batchnorm.running_mean[Co], batchnorm.running_var[Co]
+ *   then fcs.1.weight[1024,40960], fcs.1.bias, fcs.3.weight[1024,1024], fcs.3.bias,
+ *        fcs.5.weight[432,1024], fcs.5.bias
+ * BatchNorm (eps 1e-5) is folded into the convolution in f64 and rounded once to f32.
+ * max_batch = largest number of tile-forwards one call will be asked for (sizes the workspace).
+ * Synchronous (returns after the upload has completed). */
+int axt_detector_create(const float *const *h_tensors, int n_tensors, int max_batch,
+                        axt_detector **out);
+void axt_detector_destroy(axt_detector *det);
+/* bytes of device memory held by the handle (packed weights + activation workspace) */
+size_t axt_detector_device_bytes(const axt_detector *det);
+
+/* detect_axons (model.py:119-125; call site AxonDetections.py:118):
+ * d_x f32 [B,5,512,512] NCHW -> d_yolo f32 [B,12,12,3] (dim1 = x cell, dim2 = y cell,
+ * last = conf, x_in_cell, y_in_cell). B <= max_batch. */
+int axt_cnn_forward(axt_detector *det, const float *d_x, int B, float *d_yolo, void *stream);
+
+/* The same forward pass fed straight from the timelapse, fusing
+ * Timelapse.get_frametiles_stack (Timelapse.py:111-125,150-157) into the first convolution:
+ * d_frames f32 [T_all,H,W] is channel 0 of the context-padded sequence; detection frame t of
+ * tile k reads frames t..t+4 at tile origin (tile_yx[2k]*512, tile_yx[2k+1]*512), zero beyond
+ * H/W (ZeroPad2d at Timelapse.py:529-533). Output d_yolo f32 [n_frames, n_tiles, 12,12,3] for
+ * detection frames t0 .. t0+n_frames-1. n_frames*n_tiles may exceed max_batch (chunked). */
+int axt_cnn_forward_frames(axt_detector *det, const float *d_frames, int T_all, int H, int W,
+                           int t0, int n_frames, const int32_t *h_tile_yx, int n_tiles,
+                           float *d_yolo, void *stream);
+
+/* FLOPs of one tile-forward as executed (algorithmic: 2*M*N*K of the unpadded layers). */
+double axt_cnn_flops_per_tile(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Tiling: which 512x512 tiles the reference keeps (Timelapse.py:551-558): a tile is kept if
+ * any pixel of it is > 0 at any t. d_occ u8 [ceil(H/512)*ceil(W/512)] row-major, 1 = keep.
+ * ------------------------------------------------------------------------------------------ */
+int axt_tile_occupancy(const float *d_frames, int T_all, int H, int W, uint8_t *d_occ, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * YOLO grid -> frame detections. Replaces, per frame,
+ *   _yolo_Y2pandas_det  (AxonDetections.py:178-248)  decode, round-half-even, conf >= thr
+ *   stitch_tiles        (Timelapse.py:166-197)       + tile origin
+ *   _non_max_supression (AxonDetections.py:250-278)  greedy, dx^2+dy^2 < min_dist^2 dies
+ * d_yolo f32 [n_frames, n_tiles, 12,12,3]; h_tile_yx i32 [n_tiles,2] (tile row, tile col).
+ * Outputs, capacity cap >= n_tiles*144 per frame: d_conf f32, d_x i32, d_y i32 [n_frames,cap]
+ * in descending confidence (ties: tile order, then cell order), d_count i32 [n_frames].
+ * ------------------------------------------------------------------------------------------ */
+int axt_decode_stitch_nms(const float *d_yolo, int n_frames, int n_tiles, const int32_t *h_tile_yx,
+                          float conf_thr, int min_dist, int cap,
+                          float *d_conf, int32_t *d_x, int32_t *d_y, int32_t *d_count, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Association costs.
+ * ------------------------------------------------------------------------------------------ */
+/* observation_model (mincostflow_models.py:6-27) after the confidence capping of
+ * AxonDetections.py:655-659. method 0 = 'scale_to_max' (conf / max over all frames),
+ * 1 = 'ceil' (min(conf,1)). d_cost f64 [n_frames,cap] (entries >= count are untouched). */
+int axt_obs_costs(const float *d_conf, const int32_t *d_count, int n_frames, int cap,
+                  int method, double max_conf_cost, double *d_cost, void *stream);
+
+/* _compute_detections_astar_paths + _get_astar_path_distances for ONE frame pair
+ * (AxonDetections.py:526-629,717-752; A* call utils.py:379): D[i,j] = number of cells on the
+ * minimum-cost 4-connected (conn8: 8-connected) path from detection i of the earlier frame
+ * (rows) to detection j of the later frame on weights {1 on mask, 65536 off}; max_dist where
+ * the euclidean distance is >= max_dist, an end point is outside the grid, or the path has
+ * more than max_dist cells. d_mask u8 [H,W] (1 = on mask) or NULL for an all-ones mask
+ * (closed form). D i32 [na, nb] row-major. */
+int axt_path_cost(const int32_t *d_xa, const int32_t *d_ya, int na,
+                  const int32_t *d_xb, const int32_t *d_yb, int nb,
+                  const uint8_t *d_mask, int H, int W, int max_dist, int conn8,
+                  int32_t *d_D, void *stream);
+
+/* All admissible transition arcs of a timelapse in one pass (what transition_model,
+ * mincostflow_models.py:67-119, and the tracker's cost_threshold keep): for every detection
+ * a of frame t and b of frame t+g (g = 1..max_gap) with D(a,b) <= h_dmax[g-1], one arc a->b.
+ * Detections are numbered globally in frame order (frame offsets = prefix sum of counts).
+ * CSR by tail: d_row_ptr i64 [n_det+1] (allocate n_frames*cap+1); d_col i32 [n_arcs] (global
+ * index of b), d_len i16 [n_arcs] (D), d_gap u8 [n_arcs]. Rows are sorted by (gap, b):
+ * deterministic. d_work i32 [n_frames*cap*max_gap + n_frames + 1 + max_gap] is scratch that
+ * must stay untouched between the two phases:
+ *   phase 1: d_col == NULL -> counts, row_ptr, *n_arcs (synchronises the stream);
+ *   phase 2: d_col/d_len/d_gap sized by *n_arcs -> filled (asynchronous).
+ * Optional integer arc costs: d_cost_units i64 [max_gap, max_dist+1] holds round(cost*1e6) of
+ * transition_model for every (gap, D); d_cost i64 [n_arcs] then receives
+ * axt_arc_cost_int-compatible values (units << 16 | hash16(3, a, b)). Both NULL to skip.
+ * d_mask must be NULL (all-ones mask) in this version; masked grids use axt_path_cost. */
+int axt_build_arcs(const int32_t *d_x, const int32_t *d_y, const int32_t *d_count, int n_frames, int cap,
+                   const uint8_t *d_mask, int H, int W, int max_dist, int conn8,
+                   int max_gap, const int32_t *h_dmax,
+                   int64_t *d_row_ptr, int32_t *d_work, int32_t *d_col, int16_t *d_len, uint8_t *d_gap,
+                   const int64_t *d_cost_units, int64_t *d_cost, int64_t *n_arcs, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Global data association. Replaces libmot's MinCostFlowTracker as driven by
+ * AxonDetections.py:663-690 (process() per frame, then compute_trajectories()).
+ * HOST function (exact successive-shortest-path min-cost flow on the unit-capacity tracking
+ * network; the solve is serial by nature -- DESIGN.md).
+ *   n_det detections numbered globally; per detection: integer observation cost;
+ *   entry/exit arcs cost h_entry[k], h_exit[k]; transition arcs in CSR (row_ptr, col, cost).
+ *   min_flow/max_flow: bounds on the number of trajectories (MCF_MIN_FLOW / MCF_MAX_FLOW).
+ * Outputs: h_next i32 [n_det]: successor detection on the same trajectory or -1;
+ *          h_track i32 [n_det]: trajectory id (numbered by first detection) or -1;
+ *          *n_tracks, *total_cost.
+ * Returns AXT_INFEASIBLE if fewer than min_flow trajectories can be routed (the reference's
+ * falsy compute_trajectories(), AxonDetections.py:691-696).
+ * ------------------------------------------------------------------------------------------ */
+int axt_mcf_solve(int n_det, const int64_t *h_obs, const int64_t *h_entry, const int64_t *h_exit,
+                  const int64_t *h_row_ptr, const int32_t *h_col, const int64_t *h_cost,
+                  int min_flow, int max_flow,
+                  int32_t *h_next, int32_t *h_track, int *n_tracks, int64_t *total_cost);
+
+/* Integer arc cost used by the flow network: round(cost * 1e6) << 16 | hash16(kind, a, b).
+ * kind 0 entry, 1 exit, 2 observation, 3 transition. The low 16 bits make the optimum unique
+ * (DESIGN.md "Unpinned third-party semantics"). */
+int64_t axt_arc_cost_int(double cost, int kind, int64_t a, int64_t b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

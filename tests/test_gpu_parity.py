@@ -1,0 +1,284 @@
+"""Parity of the HIP hot path (through the C ABI) against the golden vectors captured from the
+reference and against the CPU oracle. Run on the MI355X box: pytest -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from axtrack_amd import synth, params
+from axtrack_amd import hotpath as hp
+from oracle import oracle as orc
+from helpers import golden_dets, csr_arcs_from_oracle, tracks_from_next
+
+pytestmark = pytest.mark.gpu
+
+# f32 CNN: the reference (oneDNN), the oracle (direct loops) and the MFMA kernels sum in different
+# orders; outputs are O(1) and agree to a few 1e-6. Tolerance stated for the whole detector:
+CNN_ATOL, CNN_RTOL = 2e-4, 2e-4
+
+
+@pytest.fixture(scope='module')
+def detector(weights):
+    import axtrack_amd
+    return axtrack_amd.Detector(weights, max_batch=24)
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+# ----------------------------------------------------------------------------------------- a-1 / a-2
+def test_cnn_forward_matches_reference_golden(golden, detector):
+    g = golden('cnn_512')
+    frames = synth.synth_frames(int(g['T_all']), 512, 512, seed=int(g['frames_seed']))
+    y = detector.detect_frames(dev(frames), [(0, 0)]).cpu().numpy()
+    assert y.shape == (5, 1, 12, 12, 3)
+    np.testing.assert_allclose(y[:, 0], g['yolo'], atol=CNN_ATOL, rtol=CNN_RTOL)
+    err = np.abs(y[:, 0] - g['yolo']).max()
+    assert err < 5e-5, f'unexpectedly large deviation from the reference: {err}'
+
+
+def test_detect_axons_tensor_interface_equals_frames_path(golden, detector):
+    """detect_axons(X[B,5,512,512]) (model.py:119-125) and the fused frames path are the same kernels."""
+    g = golden('cnn_512')
+    frames = synth.synth_frames(9, 512, 512, seed=0)
+    X = np.stack([frames[t:t + 5] for t in range(5)])
+    y1 = detector.detect_axons(dev(X)).cpu().numpy()
+    y2 = detector.detect_frames(dev(frames), [(0, 0)]).cpu().numpy()[:, 0]
+    assert np.array_equal(y1, y2)
+    np.testing.assert_allclose(y1, g['yolo'], atol=CNN_ATOL, rtol=CNN_RTOL)
+    with pytest.raises(ValueError):
+        detector.detect_axons(torch.zeros(1, 5, 256, 256))
+
+
+def test_cnn_conv_stack_against_oracle_on_edge_inputs(detector, weights):
+    """Zero input, constant input and a single hot pixel in every corner: exercises the zero padding
+    of every layer and the folded-BN bias path."""
+    X = np.zeros((4, 5, 512, 512), np.float32)
+    X[1] = 1.0
+    for c, (yy, xx) in enumerate([(0, 0), (0, 511), (511, 0), (511, 511), (255, 256)]):
+        X[2, c, yy, xx] = 50.0
+    X[3] = synth.synth_frames(5, 512, 512, seed=9) * 3
+    y = detector.detect_axons(dev(X)).cpu().numpy()
+    ref = orc.cnn_forward(weights, X)
+    np.testing.assert_allclose(y, ref, atol=CNN_ATOL, rtol=CNN_RTOL)
+
+
+def test_ragged_frame_with_dropped_tile(golden, detector):
+    g = golden('detect_ragged')
+    frames = synth.synth_frames(int(g['T_all']), int(g['H']), int(g['W']), seed=int(g['frames_seed']))
+    zt = g['zero_tile']
+    frames[:, zt[0] * 512:(zt[0] + 1) * 512, zt[1] * 512:(zt[1] + 1) * 512] = 0
+    fr = dev(frames)
+    keep = hp.tile_occupancy(fr)
+    assert keep == [tuple(ix) for ix in np.argwhere(g['kept_tiles'])]
+    y = detector.detect_frames(fr, keep).cpu().numpy()
+    np.testing.assert_allclose(y, g['yolo'], atol=CNN_ATOL, rtol=CNN_RTOL)
+
+
+# ----------------------------------------------------------------------------------------- a-3 .. a-6
+@pytest.mark.parametrize('name', ['detect_1024', 'detect_ragged', 'detect_crafted'])
+def test_decode_stitch_nms_bit_exact_on_reference_grids(golden, name):
+    g = golden(name)
+    keep = [(0, 0), (0, 1), (1, 0), (1, 1)] if name == 'detect_crafted' else [tuple(ix) for ix in np.argwhere(g['kept_tiles'])]
+    conf, x, y, cnt = [t.cpu().numpy() for t in hp.decode_stitch_nms(dev(g['yolo']), keep)]
+    ref = golden_dets(g)
+    for t, (rc, rx, ry) in enumerate(ref):
+        if name == 'detect_crafted' and t == 1:
+            # exact confidence ties: the reference's order comes from pandas' unstable quicksort; ours is
+            # defined as (tile, cell) order and must equal the oracle's
+            oc, ox, oy = orc.nms(*orc.stitch(orc.decode_filter(g['yolo'][1]), keep))
+            rc, rx, ry = oc, ox, oy
+        n = int(cnt[t])
+        assert n == len(rc), f'frame {t}'
+        assert np.array_equal(conf[t, :n].view(np.uint32), rc.view(np.uint32)), f'frame {t}'
+        assert np.array_equal(x[t, :n], rx) and np.array_equal(y[t, :n], ry), f'frame {t}'
+
+
+def test_nms_empty_and_full_frames():
+    yolo = np.zeros((3, 2, 12, 12, 3), np.float32)              # frame 0: nothing passes
+    yolo[1, ..., 0] = 0.9                                        # frame 1: all cells, all at the cell origin
+    yolo[2, ..., 0] = 0.9
+    yolo[2, ..., 1:] = 0.5                                       # frame 2: cell centres, 42.7 px apart: all survive
+    keep = [(0, 0), (0, 1)]
+    conf, x, y, cnt = [t.cpu().numpy() for t in hp.decode_stitch_nms(dev(yolo), keep)]
+    ref = orc.detect_from_yolo(list(yolo), keep)
+    assert cnt[0] == 0 and cnt[2] == 288
+    for t in range(3):
+        n = int(cnt[t])
+        assert n == len(ref[t][0])
+        assert np.array_equal(x[t, :n], ref[t][1]) and np.array_equal(y[t, :n], ref[t][2])
+    with pytest.raises(Exception):
+        hp.decode_stitch_nms(dev(yolo), keep, cap=100)           # capacity below n_tiles*144
+
+
+def test_nms_adversarial_chain():
+    """A chain of detections, each within 23 px of the next, descending confidence: alternate ones
+    survive; the parallel rounds must reproduce the sequential greedy result."""
+    yolo = np.zeros((1, 1, 12, 12, 3), np.float32)
+    k = 0
+    for i in range(12):
+        for j in range(12):
+            # place along a snake with ~15 px spacing by abusing the in-cell offsets
+            px, py = 10 + 15 * (k % 30), 10 + 15 * (k // 30)
+            yolo[0, 0, i, j] = (2.0 - 0.01 * k, px * 12 / 512 - i, py * 12 / 512 - j)
+            k += 1
+    conf, x, y, cnt = [t.cpu().numpy() for t in hp.decode_stitch_nms(dev(yolo), [(0, 0)])]
+    rc, rx, ry = orc.detect_from_yolo([yolo[0]], [(0, 0)])[0]
+    n = int(cnt[0])
+    assert n == len(rc) and np.array_equal(x[0, :n], rx) and np.array_equal(y[0, :n], ry)
+
+
+# ----------------------------------------------------------------------------------------- a-8 / a-10
+def test_observation_costs(golden):
+    g, a = golden('detect_1024'), golden('assoc_parts')
+    dets = golden_dets(g)
+    F, cap = len(dets), 576
+    conf = np.zeros((F, cap), np.float32)
+    for t, d in enumerate(dets):
+        conf[t, :len(d[0])] = d[0]
+    cnt = np.array([len(d[0]) for d in dets], np.int32)
+    cost = hp.obs_costs(dev(conf), dev(cnt), 'scale_to_max', 4.6).cpu().numpy()
+    flat = np.concatenate([cost[t, :cnt[t]] for t in range(F)])
+    # f64 log on the GPU is accurate to 1 ulp, not correctly rounded: tolerance 1e-12, and the
+    # integer cost units (round(cost*1e6)) must be identical
+    np.testing.assert_allclose(flat, a['obs_cost'], rtol=0, atol=1e-12)
+    assert np.array_equal(np.rint(flat * 1e6), np.rint(a['obs_cost'] * 1e6))
+    ceil = hp.obs_costs(dev(conf), dev(cnt), 'ceil', 4.6).cpu().numpy()
+    ref = orc.observation_cost(a['conf_ceil'])
+    np.testing.assert_allclose(np.concatenate([ceil[t, :cnt[t]] for t in range(F)]), ref, rtol=0, atol=1e-12)
+
+
+# ----------------------------------------------------------------------------------------- a-9 / a-11
+def test_path_cost_open_grid_matches_oracle(golden):
+    g = golden('detect_1024')
+    dets = golden_dets(g)
+    (c0, x0, y0), (c1, x1, y1) = dets[0], dets[1]
+    x0 = x0.copy(); x0[0] = -3                                    # an anchor outside the grid (decode does not clamp)
+    for conn8 in (False, True):
+        D = hp.path_cost(dev(x0, torch.int32), dev(y0, torch.int32), dev(x1, torch.int32), dev(y1, torch.int32),
+                         1024, 1024, None, 500, conn8).cpu().numpy()
+        ref = orc.path_matrix((c0, x0, y0), (c1, x1, y1), 1024, 1024, None, 500, conn8)
+        assert np.array_equal(D, ref)
+    assert (D[0] == 500).all()
+
+
+def test_build_arcs_matches_oracle_csr(golden):
+    g = golden('detect_1024')
+    dets = golden_dets(g)
+    F, cap = len(dets), 576
+    x = np.zeros((F, cap), np.int32); y = np.zeros((F, cap), np.int32)
+    for t, d in enumerate(dets):
+        x[t, :len(d[1])] = d[1]; y[t, :len(d[2])] = d[2]
+    cnt = np.array([len(d[0]) for d in dets], np.int32)
+    from axtrack_amd.detections import transition_cost_table
+    table, dmax = transition_cost_table(params.DEPLOYED)
+    units = np.where(np.isfinite(table), np.rint(table * 1e6), 0).astype(np.int64)
+    row_ptr, col, length, gap, cost = hp.build_arcs(dev(x), dev(y), dev(cnt), 1024, 1024, dmax, units)
+    r_row, r_col, r_len, r_gap, r_cost, offs = csr_arcs_from_oracle(dets, 1024, 1024)
+    n_det = int(offs[-1])
+    assert np.array_equal(row_ptr[:n_det + 1].cpu().numpy(), r_row)
+    assert np.array_equal(col.cpu().numpy(), r_col)
+    assert np.array_equal(length.cpu().numpy(), r_len)
+    assert np.array_equal(gap.cpu().numpy(), r_gap)
+    assert np.array_equal(cost.cpu().numpy(), r_cost)
+
+
+# ----------------------------------------------------------------------------------------- whole path
+def _run_inference(frames, weights, P, name='synth'):
+    import axtrack_amd
+    model = axtrack_amd.Detector(weights, max_batch=32)
+    tl = axtrack_amd.Timelapse(frames, name=name)
+    return axtrack_amd.inference(tl, model, None, P, None, None, None)
+
+
+def test_inference_end_to_end_against_oracle(weights):
+    """1024x1024x12 (8 detection frames, 4 tiles): every stage after the CNN is bit-exact against the
+    oracle fed with the same YOLO grids; the CNN itself is within tolerance of the oracle."""
+    frames = synth.synth_frames(12, 1024, 1024, seed=11)
+    P = params.load_parameters()
+    ad = _run_inference(frames, weights, P)
+    yolo = ad._yolo.cpu().numpy()
+    ref = orc.inference(frames, weights, P=orc.DEFAULTS, yolo=list(yolo))
+    cnt, conf, x, y = ad._host_dets()
+    for t, (rc, rx, ry) in enumerate(ref['dets']):
+        n = int(cnt[t])
+        assert n == len(rc)
+        assert np.array_equal(conf[t, :n], rc) and np.array_equal(x[t, :n], rx) and np.array_equal(y[t, :n], ry)
+    assert ad.mcf_total_cost == ref['total_cost'] and ad.n_ids == len(ref['trajs'])
+    got_tracks = tracks_from_next(np.zeros(len(ad._track_flat)), ad._track_flat, ad._offs)
+    assert got_tracks == ref['trajs']
+    ids, labels, info, vals = ref['ided_all']
+    df = ad.IDed_dets_all
+    assert list(df.index) == [f'Axon_{i:0>3}' for i in ids]
+    assert [c[0] for c in df.columns] == list(labels.astype(int)) and [c[1] for c in df.columns] == list(info)
+    assert np.array_equal(np.nan_to_num(df.to_numpy(), nan=-1), np.nan_to_num(vals, nan=-1))
+    # astar_dists API (the reference's cache format) against the oracle's matrices
+    dists = ad.astar_dists()
+    refD = orc.all_path_matrices(ref['dets'], 1024, 1024)
+    assert dists.keys() == refD.keys()
+    for k in dists:
+        assert np.array_equal(dists[k], refD[k]), k
+    # one frame of the CNN against the oracle
+    yref = orc.cnn_forward(weights, orc.frame_tile_stack(frames, 3, ad.tile_yx))
+    np.testing.assert_allclose(yolo[3], yref, atol=CNN_ATOL, rtol=CNN_RTOL)
+
+
+def test_ided_dets_all_reproduces_the_references_table(golden, weights):
+    """IDed_dets_all built from golden detections + the golden (synthetic) trajectories must equal the
+    DataFrame the reference produced, including the empty-frame label quirk (AxonDetections.py:833-839)."""
+    import axtrack_amd
+    from axtrack_amd.detections import AxonDetections
+    g, a = golden('detect_1024'), golden('assoc_parts')
+    dets = golden_dets(g)
+    tl = axtrack_amd.Timelapse(np.zeros((7, 1024, 1024), np.float32), name='synth')
+    ad = AxonDetections(None, tl, params.load_parameters(), None)
+    import pandas as pd
+    tabs = [pd.DataFrame({'conf': c, 'anchor_x': x, 'anchor_y': y}) for c, x, y in dets]
+    ad._set_detections_from_tables(tabs)
+    offs = np.concatenate([[0], np.cumsum(g['counts'])])
+    track = np.full(int(offs[-1]), -1, np.int32)
+    for tid, f, k in a['traj']:
+        track[offs[f] + k] = tid
+    ad._track_flat, ad._offs = track, offs
+    df = ad._agg_all_IDed_dets()
+    assert list(df.index) == list(a['ided_all_index'])
+    assert [float(c[0]) for c in df.columns] == list(a['ided_all_cols_frame'])
+    assert [c[1] for c in df.columns] == list(a['ided_all_cols_info'])
+    np.testing.assert_array_equal(df.to_numpy(), a['ided_all_values'])
+    assert df.index.name == 'axonID' and list(df.columns.names) == ['frameID', 'detInfo']
+
+
+def test_full_size_properties_c3(weights):
+    """BASELINE config 3 size (512x512x256): properties that hold at any size."""
+    frames = synth.synth_frames(256, 512, 512, seed=0)
+    P = params.load_parameters()
+    ad = _run_inference(frames, weights, P, name='c3')
+    cnt, conf, x, y = ad._host_dets()
+    assert len(cnt) == 252 and cnt.min() > 0
+    for t in range(0, 252, 17):
+        n = int(cnt[t])
+        assert np.all(np.diff(conf[t, :n].astype(np.float64)) <= 0)                     # sorted
+        d2 = (x[t, :n, None] - x[t, None, :n]).astype(np.int64) ** 2 + (y[t, :n, None] - y[t, None, :n]).astype(np.int64) ** 2
+        np.fill_diagonal(d2, 10 ** 9)
+        assert d2.min() >= 529                                                        # NMS distance
+        assert conf[t, :n].min() >= np.float32(0.55)
+    # every trajectory visits strictly increasing frames with gaps <= 2 and admissible path lengths
+    tracks = tracks_from_next(np.zeros(len(ad._track_flat)), ad._track_flat, ad._offs)
+    assert P['MCF_MIN_FLOW'] <= len(tracks) <= P['MCF_MAX_FLOW'] and len(tracks) == ad.n_ids
+    seen = set()
+    for tr in tracks:
+        for (f0, i0), (f1, i1) in zip(tr[:-1], tr[1:]):
+            g = f1 - f0
+            assert g in (1, 2)
+            D = abs(int(x[f0, i0]) - int(x[f1, i1])) + abs(int(y[f0, i0]) - int(y[f1, i1])) + 1
+            assert D <= (251 if g == 1 else 86)
+        for node in tr:
+            assert node not in seen                                                   # node-disjoint
+            seen.add(node)
+    # idempotence: a second run gives identical results (bit-reproducible kernels, unique optimum)
+    ad2 = _run_inference(frames, weights, P, name='c3')
+    assert np.array_equal(ad2._track_flat, ad._track_flat) and ad2.mcf_total_cost == ad.mcf_total_cost
+    assert torch.equal(ad2._yolo, ad._yolo)

@@ -1,0 +1,131 @@
+"""CPU-side tests of the product's host logic and of the C-ABI library (no GPU compute)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from axtrack_amd import _lib, params
+from axtrack_amd import hotpath as hp
+from axtrack_amd.detections import transition_cost_table, _arc_cost_int_vec
+from oracle import oracle as orc
+from helpers import golden_dets, csr_arcs_from_oracle, node_costs_from_oracle, tracks_from_next
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = set()
+    for fn in os.listdir(os.path.join(ROOT, 'include')):
+        if fn.endswith('.h'):
+            text = open(os.path.join(ROOT, 'include', fn)).read()
+            text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+            names |= set(re.findall(r'\b(axt_[a-z0-9_]+)\s*\(', text))
+    assert len(names) >= 14
+    for n in sorted(names):
+        assert hasattr(lib, n), f'libaxtrack_hip.so does not export {n}'
+        assert n in _lib.SIGNATURES, f'{n} has no ctypes signature in axtrack_amd/_lib.py'
+    assert lib.axt_abi_version() == 1
+
+
+def test_product_has_no_oracle_import():
+    """The oracle is test infrastructure: nothing under axtrack_amd/ may import or load it."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'axtrack_amd')):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.cpp', '.h')):
+                text = open(os.path.join(dirpath, f)).read()
+                assert 'oracle' not in text.replace('# oracle', ''), f'{f} mentions the oracle'
+                assert 'liboracle' not in text
+
+
+def test_arc_cost_int_three_implementations_agree():
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    cost = rng.uniform(-4.6, 7.0, 200)
+    a = rng.integers(0, 2 ** 20, 200)
+    b = rng.integers(0, 2 ** 20, 200)
+    for kind in range(4):
+        vec = _arc_cost_int_vec(cost, kind, a, b)
+        for i in range(200):
+            ref = orc.arc_cost_int(cost[i], kind, a[i], b[i])
+            assert ref == lib.axt_arc_cost_int(float(cost[i]), kind, int(a[i]), int(b[i])) == int(vec[i])
+
+
+def test_transition_table_matches_reference_costs(golden):
+    a = golden('assoc_parts')
+    table, dmax = transition_cost_table(params.DEPLOYED)
+    assert list(dmax) == [251, 86]
+    for g in (1, 2):
+        assert np.array_equal(table[g - 1, 1:], a[f'trans_cost_gap{g}'])
+    assert np.isinf(table[:, 500]).all()
+
+
+def _solve(dets, H, W, P=orc.DEFAULTS):
+    row_ptr, col, length, gap, cost, offs = csr_arcs_from_oracle(dets, H, W, P)
+    obs_i, en_i, ex_i, _ = node_costs_from_oracle(dets, P)
+    res = hp.mcf_solve(obs_i, en_i, ex_i, row_ptr, col, cost, P['MCF_MIN_FLOW'], P['MCF_MAX_FLOW'])
+    return res, offs
+
+
+def test_mcf_solver_matches_oracle_on_golden_detections(golden):
+    g = golden('detect_1024')
+    dets = golden_dets(g)
+    D = orc.all_path_matrices(dets, 1024, 1024)
+    trajs, total = orc.mcf_solve(dets, D)
+    res, offs = _solve(dets, 1024, 1024)
+    assert res is not None
+    nxt, track, n_tracks, tot = res
+    assert tot == total and n_tracks == len(trajs)
+    assert tracks_from_next(nxt, track, offs) == trajs
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_mcf_solver_random_tracking_graphs(seed):
+    """Random small timelapses: product solver == Bellman-Ford oracle (tracks and cost), and the
+    optimum cost equals networkx' network simplex on the same network with the flow value fixed."""
+    import networkx as nx
+    rng = np.random.default_rng(seed)
+    F = int(rng.integers(3, 9))
+    dets = []
+    for _ in range(F):
+        n = int(rng.integers(0, 9))
+        conf = np.sort(rng.uniform(0.55, 1.3, n).astype(np.float32))[::-1]
+        dets.append((conf, rng.integers(0, 400, n), rng.integers(0, 400, n)))
+    P = dict(orc.DEFAULTS, MCF_MIN_FLOW=int(rng.integers(0, 3)), MCF_MAX_FLOW=int(rng.integers(3, 12)))
+    if sum(len(d[0]) for d in dets) == 0:
+        return
+    D = orc.all_path_matrices(dets, 400, 400)
+    trajs, total = orc.mcf_solve(dets, D, P)
+    res, offs = _solve(dets, 400, 400, P)
+    if trajs is None:
+        assert res is None
+        return
+    nxt, track, n_tracks, tot = res
+    assert tot == total
+    assert tracks_from_next(nxt, track, offs) == trajs
+    # independent optimum check
+    tail, head, cost, _ = orc.build_flow_graph(dets, D, P)
+    G = nx.DiGraph()
+    Fv = len(trajs)
+    G.add_node(0, demand=-Fv); G.add_node(1, demand=Fv)
+    for t, h, c in zip(tail, head, cost):
+        G.add_edge(int(t), int(h), capacity=1, weight=int(c))
+    assert nx.min_cost_flow_cost(G) == total
+
+
+def test_mcf_infeasible_and_argument_errors():
+    dets = [(np.array([0.9], np.float32), np.array([10]), np.array([10]))]
+    P = dict(orc.DEFAULTS, MCF_MIN_FLOW=5)
+    res, _ = _solve(dets, 100, 100, P)
+    assert res is None                                     # fewer than min_flow trajectories exist
+    lib = _lib.load()
+    bad_col = np.array([0], np.int32)                      # arc pointing backwards in time
+    z = np.zeros(1, np.int64)
+    rp = np.array([0, 1], np.int64)
+    out = np.zeros(1, np.int32)
+    n, tot = ctypes.c_int(), ctypes.c_int64()
+    rc = lib.axt_mcf_solve(1, z.ctypes.data, z.ctypes.data, z.ctypes.data, rp.ctypes.data, bad_col.ctypes.data,
+                           z.ctypes.data, 0, 1, out.ctypes.data, out.ctypes.data, ctypes.byref(n), ctypes.byref(tot))
+    assert rc == -22 and b'forward in time' in lib.axt_last_error()
