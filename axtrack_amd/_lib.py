@@ -22,6 +22,9 @@ SIGNATURES = {
     'axt_cnn_forward_frames': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                        c_void_p, c_void_p]),
     'axt_cnn_flops_per_tile': (c_double, []),
+    'axt_detector_set_profiling': (c_int, [c_void_p, c_int]),
+    'axt_detector_read_profile': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
+    'axt_cnn_kernel_flops_per_tile': (c_double, [c_int]),
     'axt_tile_occupancy': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'axt_decode_stitch_nms': (c_int, [c_void_p, c_int, c_int, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_void_p]),
@@ -33,6 +36,8 @@ SIGNATURES = {
                                c_void_p, c_void_p, ctypes.POINTER(c_int64), c_void_p]),
     'axt_mcf_solve': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                               c_void_p, c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int64)]),
+    'axt_hungarian_assoc': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                    c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     'axt_arc_cost_int': (c_int64, [c_double, c_int, c_int64, c_int64]),
 }
 

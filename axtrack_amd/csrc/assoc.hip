@@ -186,6 +186,13 @@ __global__ void row_ptr_kernel(const int *__restrict__ cnt, const int *__restric
 
 }  // namespace
 
+int axt_frame_offsets(const int32_t *d_count, int n_frames, int cap, int32_t *d_off, hipStream_t st)
+{
+    hipLaunchKernelGGL(frame_offsets_kernel, dim3(1), dim3(1024), 0, st, d_count, n_frames, cap, d_off);
+    AXT_LAUNCH_CHECK();
+    return AXT_OK;
+}
+
 extern "C" {
 
 int axt_obs_costs(const float *d_conf, const int32_t *d_count, int n_frames, int cap, int method, double max_conf_cost,

@@ -333,9 +333,47 @@ struct axt_detector {
     float *d_act[8] = {};       // activations after conv block i (chunk-sized for i < 4)
     float *d_slab = nullptr, *d_fc1 = nullptr, *d_fc2 = nullptr;
     size_t bytes = 0;
+    // optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg)
+    bool profiling = false;
+    struct Span { hipEvent_t a, b; int kernel; int items; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> free_events;
 };
 
 namespace {
+
+hipEvent_t take_event(axt_detector *d)
+{
+    if (!d->free_events.empty()) {
+        hipEvent_t e = d->free_events.back();
+        d->free_events.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+// RAII: records an event before and after one kernel launch when profiling is on
+struct ProfSpan {
+    axt_detector *d;
+    hipStream_t st;
+    hipEvent_t a = nullptr, b = nullptr;
+    int kernel, items;
+    ProfSpan(axt_detector *d_, hipStream_t st_, int kernel_, int items_) : d(d_), st(st_), kernel(kernel_), items(items_)
+    {
+        if (!d->profiling) return;
+        a = take_event(d);
+        b = take_event(d);
+        (void)hipEventRecord(a, st);
+    }
+    ~ProfSpan()
+    {
+        if (!a) return;
+        (void)hipEventRecord(b, st);
+        d->spans.push_back({a, b, kernel, items});
+    }
+};
 
 template <typename T>
 int dev_alloc(axt_detector *d, T **p, size_t n)
@@ -434,16 +472,31 @@ int run_front(axt_detector *d, const float *frames, int Hf, int Wf, int t0, int 
               const TileList &tl, int nb, float *act4_out, hipStream_t st)
 {
     int rc;
-    if ((rc = launch_conv<5, 20, 2, false, 8, 4, 2, true>(frames, d->d_wconv[0], d->d_bconv[0], d->d_act[0], 512, 1,
-                                                          nb, st, Hf, Wf, t0, tstep, item0, n_tiles, &tl))) return rc;
-    if ((rc = launch_conv<20, 40, 2, false, 4, 4, 3, false>(d->d_act[0], d->d_wconv[1], d->d_bconv[1], d->d_act[1],
-                                                            256, 1, nb, st))) return rc;
-    if ((rc = launch_conv<40, 80, 1, true, 8, 4, 5, false>(d->d_act[1], d->d_wconv[2], d->d_bconv[2], d->d_act[2],
-                                                           128, 1, nb, st))) return rc;
-    if ((rc = launch_conv<80, 80, 1, false, 8, 4, 5, false>(d->d_act[2], d->d_wconv[3], d->d_bconv[3], d->d_act[3],
-                                                            64, 1, nb, st))) return rc;
-    if ((rc = launch_conv<80, 80, 1, true, 8, 4, 5, false>(d->d_act[3], d->d_wconv[4], d->d_bconv[4], act4_out, 64,
-                                                           1, nb, st))) return rc;
+    {
+        ProfSpan ps(d, st, 0, nb);
+        if ((rc = launch_conv<5, 20, 2, false, 8, 4, 2, true>(frames, d->d_wconv[0], d->d_bconv[0], d->d_act[0], 512, 1,
+                                                              nb, st, Hf, Wf, t0, tstep, item0, n_tiles, &tl))) return rc;
+    }
+    {
+        ProfSpan ps(d, st, 1, nb);
+        if ((rc = launch_conv<20, 40, 2, false, 4, 4, 3, false>(d->d_act[0], d->d_wconv[1], d->d_bconv[1], d->d_act[1],
+                                                                256, 1, nb, st))) return rc;
+    }
+    {
+        ProfSpan ps(d, st, 2, nb);
+        if ((rc = launch_conv<40, 80, 1, true, 8, 4, 5, false>(d->d_act[1], d->d_wconv[2], d->d_bconv[2], d->d_act[2],
+                                                               128, 1, nb, st))) return rc;
+    }
+    {
+        ProfSpan ps(d, st, 3, nb);
+        if ((rc = launch_conv<80, 80, 1, false, 8, 4, 5, false>(d->d_act[2], d->d_wconv[3], d->d_bconv[3], d->d_act[3],
+                                                                64, 1, nb, st))) return rc;
+    }
+    {
+        ProfSpan ps(d, st, 4, nb);
+        if ((rc = launch_conv<80, 80, 1, true, 8, 4, 5, false>(d->d_act[3], d->d_wconv[4], d->d_bconv[4], act4_out, 64,
+                                                               1, nb, st))) return rc;
+    }
     return AXT_OK;
 }
 
@@ -451,18 +504,45 @@ int run_front(axt_detector *d, const float *frames, int Hf, int Wf, int t0, int 
 int run_back(axt_detector *d, int nb, float *d_yolo, hipStream_t st)
 {
     int rc;
-    if ((rc = launch_conv<80, 80, 1, false, 8, 4, 5, false>(d->d_act[4], d->d_wconv[5], d->d_bconv[5], d->d_act[5],
-                                                            32, 1, nb, st))) return rc;
-    if ((rc = launch_conv<80, 80, 1, true, 8, 4, 5, false>(d->d_act[5], d->d_wconv[6], d->d_bconv[6], d->d_act[6],
-                                                           32, 1, nb, st))) return rc;
-    if ((rc = launch_conv<80, 160, 1, false, 8, 4, 5, false>(d->d_act[6], d->d_wconv[7], d->d_bconv[7], d->d_act[7],
-                                                             16, 2, nb, st))) return rc;
-    if ((rc = launch_gemm(d->d_act[7], kFeat, d->d_wfc[0], kFc, d->d_slab, nb, kFeat, kFc1Split, st))) return rc;
-    if ((rc = launch_reduce(d->d_slab, kFc1Split, nb, kFc, kFc, d->d_bfc[0], 1, d->d_fc1, st))) return rc;
-    if ((rc = launch_gemm(d->d_fc1, kFc, d->d_wfc[1], kFc, d->d_slab, nb, kFc, kFc2Split, st))) return rc;
-    if ((rc = launch_reduce(d->d_slab, kFc2Split, nb, kFc, kFc, d->d_bfc[1], 1, d->d_fc2, st))) return rc;
-    if ((rc = launch_gemm(d->d_fc2, kFc, d->d_wfc[2], kOutPad, d->d_slab, nb, kFc, kFc3Split, st))) return rc;
-    if ((rc = launch_reduce(d->d_slab, kFc3Split, nb, kOutPad, kOut, d->d_bfc[2], 0, d_yolo, st))) return rc;
+    {
+        ProfSpan ps(d, st, 5, nb);
+        if ((rc = launch_conv<80, 80, 1, false, 8, 4, 5, false>(d->d_act[4], d->d_wconv[5], d->d_bconv[5], d->d_act[5],
+                                                                32, 1, nb, st))) return rc;
+    }
+    {
+        ProfSpan ps(d, st, 6, nb);
+        if ((rc = launch_conv<80, 80, 1, true, 8, 4, 5, false>(d->d_act[5], d->d_wconv[6], d->d_bconv[6], d->d_act[6],
+                                                               32, 1, nb, st))) return rc;
+    }
+    {
+        ProfSpan ps(d, st, 7, nb);
+        if ((rc = launch_conv<80, 160, 1, false, 8, 4, 5, false>(d->d_act[6], d->d_wconv[7], d->d_bconv[7], d->d_act[7],
+                                                                 16, 2, nb, st))) return rc;
+    }
+    {
+        ProfSpan ps(d, st, 8, nb);
+        if ((rc = launch_gemm(d->d_act[7], kFeat, d->d_wfc[0], kFc, d->d_slab, nb, kFeat, kFc1Split, st))) return rc;
+    }
+    {
+        ProfSpan ps(d, st, 9, nb);
+        if ((rc = launch_reduce(d->d_slab, kFc1Split, nb, kFc, kFc, d->d_bfc[0], 1, d->d_fc1, st))) return rc;
+    }
+    {
+        ProfSpan ps(d, st, 10, nb);
+        if ((rc = launch_gemm(d->d_fc1, kFc, d->d_wfc[1], kFc, d->d_slab, nb, kFc, kFc2Split, st))) return rc;
+    }
+    {
+        ProfSpan ps(d, st, 11, nb);
+        if ((rc = launch_reduce(d->d_slab, kFc2Split, nb, kFc, kFc, d->d_bfc[1], 1, d->d_fc2, st))) return rc;
+    }
+    {
+        ProfSpan ps(d, st, 12, nb);
+        if ((rc = launch_gemm(d->d_fc2, kFc, d->d_wfc[2], kOutPad, d->d_slab, nb, kFc, kFc3Split, st))) return rc;
+    }
+    {
+        ProfSpan ps(d, st, 13, nb);
+        if ((rc = launch_reduce(d->d_slab, kFc3Split, nb, kOutPad, kOut, d->d_bfc[2], 0, d_yolo, st))) return rc;
+    }
     return AXT_OK;
 }
 
@@ -570,10 +650,53 @@ void axt_detector_destroy(axt_detector *d)
     (void)hipFree(d->d_slab);
     (void)hipFree(d->d_fc1);
     (void)hipFree(d->d_fc2);
+    for (auto &sp : d->spans) {
+        (void)hipEventDestroy(sp.a);
+        (void)hipEventDestroy(sp.b);
+    }
+    for (hipEvent_t e : d->free_events) (void)hipEventDestroy(e);
     delete d;
 }
 
 size_t axt_detector_device_bytes(const axt_detector *d) { return d ? d->bytes : 0; }
+
+int axt_detector_set_profiling(axt_detector *d, int on)
+{
+    AXT_REQUIRE(d, "null argument");
+    d->profiling = on != 0;
+    return AXT_OK;
+}
+
+int axt_detector_read_profile(axt_detector *d, double *ms, int64_t *launches, int64_t *items, int n)
+{
+    AXT_REQUIRE(d && ms && launches && items && n >= AXT_N_CNN_KERNELS, "bad argument");
+    for (int i = 0; i < n; ++i) { ms[i] = 0; launches[i] = 0; items[i] = 0; }
+    for (auto &sp : d->spans) {
+        AXT_CHECK_HIP(hipEventSynchronize(sp.b));
+        float t = 0.f;
+        AXT_CHECK_HIP(hipEventElapsedTime(&t, sp.a, sp.b));
+        ms[sp.kernel] += t;
+        launches[sp.kernel] += 1;
+        items[sp.kernel] += sp.items;
+        d->free_events.push_back(sp.a);
+        d->free_events.push_back(sp.b);
+    }
+    d->spans.clear();
+    return AXT_OK;
+}
+
+double axt_cnn_kernel_flops_per_tile(int kernel)
+{
+    if (kernel < 0 || kernel >= AXT_N_CNN_KERNELS) return 0;
+    if (kernel < 8) {
+        const ConvSpec &c = kConv[kernel];
+        const double ho = c.hin / c.stride;
+        return 2.0 * ho * ho * c.cout * c.cin * 9;
+    }
+    const double f[6] = {2.0 * kFeat * kFc, (double)kFc1Split * kFc, 2.0 * kFc * kFc, (double)kFc2Split * kFc,
+                         2.0 * kFc * kOut, (double)kFc3Split * kOut};
+    return f[kernel - 8];
+}
 
 int axt_cnn_forward(axt_detector *det, const float *d_x, int B, float *d_yolo, void *stream)
 {

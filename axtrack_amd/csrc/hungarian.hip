@@ -1,0 +1,256 @@
+// Frame-to-frame Hungarian association on gfx950 (BASELINE config 3: "detection + cost-matrix + Hungarian
+// association"). A build-side variant: the reference itself only ever runs the global min-cost-flow tracker
+// (AxonDetections.py:663-690), whose cost model this variant reuses unchanged:
+//   * cost of linking detection a (frame t) to b (frame t+g) = transition_model(D(a,b), g)
+//     (mincostflow_models.py:67-119), admitted when < MCF_EDGE_COST_THR, i.e. D <= dmax[g-1];
+//   * leaving a detection without a successor costs the threshold itself, so any admitted link is preferred.
+// Pass 1 solves, independently for every frame pair (t, t+1), the rectangular assignment
+//     min sum_{matched} c(a,b) + sum_{unmatched rows} U(a)
+// exactly (Jonker-Volgenant shortest augmenting paths on integer costs); pass 2 does the same for gap 2 between
+// detections of t that found no successor in t+1 and detections of t+2 that found no predecessor in t+1
+// (MCF_MAX_NUM_MISSES = 1). A final sweep numbers the chains in (first frame, index) order.
+//
+// One wavefront per frame pair: each lane owns columns j = lane, lane+64, ...; the cost matrix is never stored --
+// c(a,b) is recomputed from the anchors (closed-form path length, table look-up, identity hash), which is cheaper
+// than reading 8 bytes. Costs are the same 64-bit integers as the flow network's (axt_arc_cost_int), so the
+// optimum is unique and any exact LSAP solver (e.g. SciPy's linear_sum_assignment) returns the same matching.
+#include "axt_common.h"
+
+namespace {
+
+constexpr long HINF = 0x3fffffffffffffffL;
+
+__device__ __forceinline__ long h_arc_cost_int(long units, int kind, long a, long b)
+{
+    unsigned long x = ((unsigned long)kind << 60) ^ ((unsigned long)a << 30) ^ (unsigned long)b;
+    x += 0x9E3779B97F4A7C15ul;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ul;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBul;
+    x ^= x >> 31;
+    return units * 65536 + (long)(x & 0xFFFFul);
+}
+
+__device__ __forceinline__ int h_path_len_open(int xa, int ya, int xb, int yb, int H, int W, int max_dist, int conn8)
+{
+    const int dx = abs(xa - xb), dy = abs(ya - yb);
+    const long d2 = (long)dx * dx + (long)dy * dy;
+    const int len = (conn8 ? max(dx, dy) : dx + dy) + 1;
+    const bool inb = xa >= 0 && xa < W && ya >= 0 && ya < H && xb >= 0 && xb < W && yb >= 0 && yb < H;
+    return (d2 < (long)max_dist * max_dist && len <= max_dist && inb) ? len : max_dist;
+}
+
+// wave-wide argmin of (key, idx): smallest key, ties to the smallest idx
+__device__ __forceinline__ void wave_argmin(long &key, int &idx)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const long k2 = __shfl_xor(key, o);
+        const int i2 = __shfl_xor(idx, o);
+        if (k2 < key || (k2 == key && i2 < idx)) { key = k2; idx = i2; }
+    }
+}
+
+// One wave per frame pair (t, t+gap). succ/pred are per detection slot [n_frames*cap]:
+//   GAP == 1: writes succ1[t*cap+i] = j or -1 and pred1[(t+1)*cap+j] = i or -1 for every slot of the pair.
+//   GAP == 2: rows = detections of t with succ1 < 0, columns = detections of t+2 with pred1 < 0;
+//             writes succ2 / pred2 the same way.
+template <int GAP>
+__global__ __launch_bounds__(64) void hungarian_pair_kernel(
+    const int *__restrict__ x, const int *__restrict__ y, const int *__restrict__ count,
+    const int *__restrict__ frame_off, int n_frames, int cap, int H, int W, int max_dist, int conn8,
+    int dmax, const long *__restrict__ units, long thr_units,
+    const int *__restrict__ succ1, const int *__restrict__ pred1,
+    int *__restrict__ succ_out, int *__restrict__ pred_out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
+    const int t = blockIdx.x, tb = t + GAP, lane = threadIdx.x;
+    if (tb >= n_frames) return;
+    const int n = min(count[t], cap), m = min(count[tb], cap);
+    long *v = reinterpret_cast<long *>(hsm);            // [cap] column duals
+    long *spc = v + cap;                                // [cap]
+    long *u = spc + cap;                                // [cap] row duals
+    int *row4col = reinterpret_cast<int *>(u + cap);    // [cap]
+    int *col4row = row4col + cap;                       // [cap]  (-1 unassigned, -2 own dummy)
+    int *pred = col4row + cap;                          // [cap]
+    int *sr = pred + cap;                               // [cap] rows scanned in this search
+    int *xs = sr + cap, *ys = xs + cap;                 // [cap] column anchors
+    unsigned char *in_sc = reinterpret_cast<unsigned char *>(ys + cap);       // [cap]
+    unsigned char *col_ok = in_sc + cap;                // [cap] column takes part
+
+    const long a0 = frame_off[t], b0 = frame_off[tb];
+    for (int j = lane; j < m; j += 64) {
+        v[j] = 0;
+        row4col[j] = -1;
+        xs[j] = x[(long)tb * cap + j];
+        ys[j] = y[(long)tb * cap + j];
+        col_ok[j] = (GAP == 1) ? 1 : (pred1[(long)tb * cap + j] < 0);
+    }
+    for (int i = lane; i < n; i += 64) {
+        u[i] = 0;
+        col4row[i] = -1;
+    }
+    __syncthreads();
+
+    for (int i = 0; i < n; ++i) {
+        if (GAP == 2 && succ1[(long)t * cap + i] >= 0) continue;      // wave-uniform
+        for (int j = lane; j < m; j += 64) { spc[j] = HINF; in_sc[j] = 0; }
+        __syncthreads();
+        long minVal = 0, best_dummy = HINF;
+        int cur = i, dummy_row = -1, n_sr = 0, sink = -1;             // sink >= 0: real column; -2: dummy of dummy_row
+        for (;;) {
+            if (lane == 0) sr[n_sr] = cur;
+            ++n_sr;
+            const long ucur = u[cur];
+            const long rd = minVal + h_arc_cost_int(thr_units, 1, a0 + cur, 0) - ucur;
+            if (rd < best_dummy) { best_dummy = rd; dummy_row = cur; }
+            const int xa = x[(long)t * cap + cur], ya = y[(long)t * cap + cur];
+            long bkey = HINF;
+            int bidx = 0x7fffffff;
+            for (int j = lane; j < m; j += 64) {
+                if (in_sc[j] || !col_ok[j]) continue;
+                const int d = h_path_len_open(xa, ya, xs[j], ys[j], H, W, max_dist, conn8);
+                long s = spc[j];
+                if (d <= dmax) {
+                    const long c = h_arc_cost_int(units[d], 3, a0 + cur, b0 + j);
+                    const long r = minVal + c - ucur - v[j];
+                    if (r < s) { s = r; spc[j] = r; pred[j] = cur; }
+                }
+                if (s < bkey) { bkey = s; bidx = j; }
+            }
+            wave_argmin(bkey, bidx);
+            if (best_dummy <= bkey) { sink = -2; minVal = best_dummy; break; }
+            minVal = bkey;
+            if (lane == 0) in_sc[bidx] = 1;
+            __syncthreads();
+            if (row4col[bidx] < 0) { sink = bidx; break; }
+            cur = row4col[bidx];
+        }
+        __syncthreads();
+        // dual update (Crouse 2016, Alg. 1): rows of SR, columns of SC
+        for (int k = lane; k < n_sr; k += 64) {
+            const int r = sr[k];
+            u[r] += (k == 0) ? minVal : minVal - spc[col4row[r]];
+        }
+        for (int j = lane; j < m; j += 64)
+            if (in_sc[j] && j != sink) v[j] -= minVal - spc[j];
+        __syncthreads();
+        // augment back to row i
+        if (lane == 0) {
+            int r, jnew;
+            if (sink == -2) { r = dummy_row; jnew = -2; }
+            else { r = pred[sink]; jnew = sink; }
+            for (;;) {
+                const int jprev = col4row[r];
+                col4row[r] = jnew;
+                if (jnew >= 0) row4col[jnew] = r;
+                if (r == i) break;
+                jnew = jprev;
+                r = pred[jnew];
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = lane; i < n; i += 64) {
+        const bool active = (GAP == 1) || (succ1[(long)t * cap + i] < 0);
+        succ_out[(long)t * cap + i] = (active && col4row[i] >= 0) ? col4row[i] : -1;
+    }
+    for (int j = lane; j < m; j += 64) pred_out[(long)tb * cap + j] = row4col[j];
+}
+
+// chains -> track ids, numbered by (first frame, index). One block, frames in order.
+__global__ __launch_bounds__(1024) void chain_ids_kernel(const int *__restrict__ count, int n_frames, int cap,
+                                                         const int *__restrict__ pred1, const int *__restrict__ pred2,
+                                                         int *__restrict__ track, int *__restrict__ n_tracks)
+{
+    __shared__ int next_id;
+    __shared__ int wtot[16];
+    if (threadIdx.x == 0) next_id = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int t = 0; t < n_frames; ++t) {
+        const int n = min(count[t], cap);
+        for (int i0 = 0; i0 < n; i0 += 1024) {
+            const int i = i0 + threadIdx.x;
+            int id = -1;
+            bool fresh = false;
+            if (i < n) {
+                const int p1 = (t >= 1) ? pred1[(long)t * cap + i] : -1;
+                const int p2 = (t >= 2) ? pred2[(long)t * cap + i] : -1;
+                if (p1 >= 0) id = track[(long)(t - 1) * cap + p1];
+                else if (p2 >= 0) id = track[(long)(t - 2) * cap + p2];
+                else fresh = true;
+            }
+            const unsigned long long mk = __ballot(fresh);
+            if (lane == 0) wtot[wave] = __popcll(mk);
+            __syncthreads();
+            int off = next_id;
+            for (int w = 0; w < wave; ++w) off += wtot[w];
+            if (fresh) id = off + __popcll(mk & ((1ull << lane) - 1ull));
+            if (i < n) track[(long)t * cap + i] = id;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int s = 0;
+                for (int w = 0; w < 16; ++w) s += wtot[w];
+                next_id += s;
+            }
+            __syncthreads();
+        }
+        for (int i = n + threadIdx.x; i < cap; i += 1024) track[(long)t * cap + i] = -1;
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_tracks = next_id;
+}
+
+__global__ void fill_int_kernel(int *p, long n, int v)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+}  // namespace
+
+int axt_frame_offsets(const int32_t *d_count, int n_frames, int cap, int32_t *d_off, hipStream_t st);
+
+extern "C" int axt_hungarian_assoc(const int32_t *d_x, const int32_t *d_y, const int32_t *d_count, int n_frames, int cap,
+                                   int H, int W, int max_dist, int conn8, int max_gap, const int32_t *h_dmax,
+                                   const int64_t *d_cost_units, int64_t thr_units, int32_t *d_work, int32_t *d_track,
+                                   int32_t *d_n_tracks, void *stream)
+{
+    AXT_REQUIRE(d_x && d_y && d_count && h_dmax && d_cost_units && d_work && d_track && d_n_tracks, "null argument");
+    AXT_REQUIRE(n_frames >= 1 && cap >= 1 && cap <= 2048, "axt_hungarian_assoc: cap %d out of range [1,2048]", cap);
+    AXT_REQUIRE(max_gap == 1 || max_gap == 2, "axt_hungarian_assoc: max_gap must be 1 or 2");
+    hipStream_t st = (hipStream_t)stream;
+    const long slots = (long)n_frames * cap;
+    // d_work: succ1 | pred1 | succ2 | pred2 [slots each] | frame_off [n_frames+1]
+    int *succ1 = d_work, *pred1 = succ1 + slots, *succ2 = pred1 + slots, *pred2 = succ2 + slots;
+    int *frame_off = pred2 + slots;
+    hipLaunchKernelGGL(fill_int_kernel, dim3((unsigned)((4 * slots + 255) / 256)), dim3(256), 0, st, succ1, 4 * slots, -1);
+    AXT_LAUNCH_CHECK();
+    int rc = axt_frame_offsets(d_count, n_frames, cap, frame_off, st);
+    if (rc) return rc;
+    const size_t lds = (size_t)cap * (3 * 8 + 6 * 4 + 2);
+    static bool attr = false;
+    if (!attr) {
+        AXT_CHECK_HIP(hipFuncSetAttribute((const void *)hungarian_pair_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2048 * 50));
+        AXT_CHECK_HIP(hipFuncSetAttribute((const void *)hungarian_pair_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2048 * 50));
+        attr = true;
+    }
+    if (n_frames > 1) {
+        hipLaunchKernelGGL(hungarian_pair_kernel<1>, dim3(n_frames - 1), dim3(64), lds, st, d_x, d_y, d_count, frame_off,
+                           n_frames, cap, H, W, max_dist, conn8, h_dmax[0], (const long *)d_cost_units, (long)thr_units,
+                           (const int *)nullptr, (const int *)nullptr, succ1, pred1);
+        AXT_LAUNCH_CHECK();
+    }
+    if (max_gap == 2 && n_frames > 2) {
+        hipLaunchKernelGGL(hungarian_pair_kernel<2>, dim3(n_frames - 2), dim3(64), lds, st, d_x, d_y, d_count, frame_off,
+                           n_frames, cap, H, W, max_dist, conn8, h_dmax[1],
+                           (const long *)d_cost_units + (max_dist + 1), (long)thr_units, (const int *)succ1,
+                           (const int *)pred1, succ2, pred2);
+        AXT_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(chain_ids_kernel, dim3(1), dim3(1024), 0, st, d_count, n_frames, cap, (const int *)pred1,
+                       (const int *)pred2, d_track, d_n_tracks);
+    AXT_LAUNCH_CHECK();
+    return AXT_OK;
+}

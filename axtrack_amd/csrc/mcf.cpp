@@ -10,9 +10,20 @@
 // in F, so successive shortest augmenting paths stop exactly at that optimum:
 //   push while F < min_flow, or while F < max_flow and the next path has negative cost.
 //
-// Shortest paths: the network is a DAG in frame order, so the first potentials come from one DP sweep;
-// afterwards Dijkstra on reduced costs (Johnson potentials), stopped as soon as T is settled.
+// Two exact solvers share this file:
+//   * solve_lsap (fast path). Without the bound on F the problem is a sparse rectangular assignment: row k = the
+//     "out slot" of detection k, matched to the in-slot R_b of a successor b (cost obs_k + trans_kb: b's entry
+//     cost is refunded), to its own in-slot R_k (cost 0: k unused) or to a private exit column X_k
+//     (cost obs_k + entry_k + exit_k). Rows are inserted in frame order by shortest augmenting paths on reduced
+//     costs (Jonker-Volgenant / Crouse); a search ends at the first free column and X_k is always free, so
+//     searches stay local instead of sweeping the whole network. Its optimum is the flow optimum over all F.
+//   * solve_ssp (general path): successive shortest s-t paths with Johnson potentials (first potentials from one
+//     DP sweep over the frame-ordered DAG). Used when the unconstrained optimum has F outside [min_flow, max_flow].
+// Arc costs carry a 16-bit identity hash (axt_arc_cost_int) that makes the optimum unique, so both solvers (and
+// any other exact solver) return the same trajectories.
 #include <stdint.h>
+#include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 
 #include <algorithm>
@@ -136,6 +147,101 @@ struct Solver {
     }
 };
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Sparse rectangular assignment by shortest augmenting paths. Columns: [0,n) = R_b, [n,2n) = X_k.
+// ---------------------------------------------------------------------------------------------------------
+struct Lsap {
+    int n;
+    const int64_t *obs, *entry, *exitc, *row_ptr, *cost;
+    const int32_t *col;
+    std::vector<int64_t> u, v;             // duals of rows / columns
+    std::vector<int32_t> col4row, row4col; // matching
+    std::vector<int32_t> arc4row;          // transition arc used by row (or -1)
+    // per-search scratch, reset through the touched lists
+    std::vector<int64_t> spc;              // shortest path cost to a column
+    std::vector<int32_t> pred_row, pred_arc;
+    std::vector<uint8_t> in_sc;
+    std::vector<int32_t> touched_cols, sr_rows;
+
+    void run()
+    {
+        u.assign(n, 0);
+        v.assign(2 * (size_t)n, 0);
+        col4row.assign(n, -1);
+        arc4row.assign(n, -1);
+        row4col.assign(2 * (size_t)n, -1);
+        spc.assign(2 * (size_t)n, INF);
+        pred_row.assign(2 * (size_t)n, -1);
+        pred_arc.assign(2 * (size_t)n, -1);
+        in_sc.assign(2 * (size_t)n, 0);
+        typedef std::pair<int64_t, int32_t> Item;
+        std::priority_queue<Item, std::vector<Item>, std::greater<Item>> pq;
+        for (int i = 0; i < n; ++i) {
+            while (!pq.empty()) pq.pop();
+            int64_t minVal = 0;
+            int cur = i, sink = -1;
+            sr_rows.clear();
+            while (sink < 0) {
+                sr_rows.push_back(cur);
+                auto relax = [&](int j, int64_t c, int32_t arc) {
+                    if (in_sc[j]) return;
+                    const int64_t r = minVal + c - u[cur] - v[j];
+                    if (r < spc[j]) {
+                        if (spc[j] == INF) touched_cols.push_back(j);
+                        spc[j] = r;
+                        pred_row[j] = cur;
+                        pred_arc[j] = arc;
+                        pq.push(Item(r, j));
+                    }
+                };
+                relax(cur, 0, -1);                                               // stay unused
+                relax(n + cur, obs[cur] + entry[cur] + exitc[cur], -1);          // a track of its own / track end
+                const int64_t base = obs[cur] + entry[cur];
+                for (int64_t e = row_ptr[cur]; e < row_ptr[cur + 1]; ++e)
+                    relax(col[e], base + cost[e] - entry[col[e]], (int32_t)e);   // k -> b, b's entry refunded
+                int j = -1;
+                while (!pq.empty()) {
+                    const Item it = pq.top();
+                    pq.pop();
+                    if (in_sc[it.second] || it.first > spc[it.second]) continue;
+                    j = it.second;
+                    minVal = it.first;
+                    break;
+                }
+                // X_i is always reachable, so a column is always found
+                in_sc[j] = 1;
+                if (row4col[j] < 0) sink = j;
+                else cur = row4col[j];
+            }
+            // dual update (Crouse 2016, Alg. 1)
+            u[i] += minVal;
+            for (size_t k = 1; k < sr_rows.size(); ++k) {
+                const int r = sr_rows[k];
+                u[r] += minVal - spc[col4row[r]];
+            }
+            for (int32_t j : touched_cols)
+                if (in_sc[j]) v[j] -= minVal - spc[j];
+            // augment
+            int j = sink;
+            for (;;) {
+                const int r = pred_row[j];
+                row4col[j] = r;
+                const int prev = col4row[r];
+                col4row[r] = j;
+                arc4row[r] = pred_arc[j];
+                if (r == i) break;
+                j = prev;
+            }
+            dbg_rows += sr_rows.size(); dbg_cols += touched_cols.size(); if (sr_rows.size() > dbg_max) dbg_max = sr_rows.size();
+            for (int32_t c : touched_cols) { spc[c] = INF; in_sc[c] = 0; }
+            touched_cols.clear();
+        }
+        if (getenv("AXT_MCF_DEBUG")) fprintf(stderr, "lsap: n=%d rows scanned=%zu cols touched=%zu max SR=%zu\n", n, dbg_rows, dbg_cols, dbg_max);
+    }
+    size_t dbg_rows = 0, dbg_cols = 0, dbg_max = 0;
+};
+
 }  // namespace
 
 extern "C" int axt_mcf_solve(int n_det, const int64_t *h_obs, const int64_t *h_entry, const int64_t *h_exit,
@@ -165,12 +271,36 @@ extern "C" int axt_mcf_solve(int n_det, const int64_t *h_obs, const int64_t *h_e
     s.pred.assign(n_det, NONE);
     s.succ.assign(n_det, NONE);
     s.pred_tail.assign(n_det, -1);
-    s.dist.assign(2 * n_det + 2, INF);
-    s.par.assign(2 * n_det + 2, -1);
-    s.par_arc.assign(2 * n_det + 2, -1);
     int F = 0;
     int64_t total = 0;
-    if (n_det > 0) {
+    bool done = false;
+    if (n_det > 0 && !getenv("AXT_MCF_FORCE_SSP")) {
+        // fast path: optimum over all flow counts as an assignment problem
+        Lsap a;
+        a.n = n_det;
+        a.obs = h_obs; a.entry = h_entry; a.exitc = h_exit; a.row_ptr = h_row_ptr; a.cost = h_cost; a.col = h_col;
+        a.run();
+        for (int k = 0; k < n_det; ++k) {
+            const int j = a.col4row[k];
+            if (j == k) continue;                                   // unused
+            total += h_obs[k];
+            if (j >= n_det) { s.succ[k] = TERMINAL; total += h_exit[k]; }
+            else { s.succ[k] = a.arc4row[k]; s.pred[j] = a.arc4row[k]; s.pred_tail[j] = k; total += h_cost[a.arc4row[k]]; }
+        }
+        for (int k = 0; k < n_det; ++k)
+            if (a.col4row[k] != k && s.pred[k] == NONE) { s.pred[k] = TERMINAL; total += h_entry[k]; ++F; }
+        done = F >= min_flow && F <= max_flow;
+        if (!done) {
+            std::fill(s.pred.begin(), s.pred.end(), NONE);
+            std::fill(s.succ.begin(), s.succ.end(), NONE);
+            F = 0;
+            total = 0;
+        }
+    }
+    if (n_det > 0 && !done) {
+        s.dist.assign(2 * n_det + 2, INF);
+        s.par.assign(2 * n_det + 2, -1);
+        s.par_arc.assign(2 * n_det + 2, -1);
         s.init_potentials();
         while (F < max_flow) {
             if (!s.dijkstra()) break;

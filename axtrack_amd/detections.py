@@ -69,7 +69,9 @@ class AxonDetections(object):
         self._det_tables = None
 
     def __len__(self):
-        return len(self.timepoint_subset)
+        """Number of detection frames (after a multi-GPU gather: of the whole timelapse)."""
+        d_count = getattr(self, 'd_count', None)
+        return int(d_count.shape[0]) if d_count is not None else len(self.timepoint_subset)
 
     # ------------------------------------------------------------------ caches (AxonDetections.py:141-176)
     def _cache_fname(self, which):
@@ -92,7 +94,7 @@ class AxonDetections(object):
         self.tile_yx = hp.tile_occupancy(frames)
         if not self.tile_yx:
             raise ValueError('the timelapse is empty (no tile has a non-zero pixel)')
-        self._yolo = self.model.detect_frames(frames, self.tile_yx, 0, len(self))
+        self._yolo = self.model.detect_frames(frames, self.tile_yx, 0, self.dataset.sizet)
         thr = float(np.float32(self.all_conf_thrs.min()))
         self.d_conf, self.d_x, self.d_y, self.d_count = hp.decode_stitch_nms(
             self._yolo, self.tile_yx, thr, self.nms_min_dist)
@@ -100,6 +102,15 @@ class AxonDetections(object):
         self._host = None
         if cache == 'to':
             self.to_cache('_detections', self._detections)
+
+    def gather_detections(self, group=None):
+        """Frame-sharded runs: every rank has detected its own contiguous block of frames; one
+        all-gather (RCCL over xGMI on GPUs) gives every rank the detections of the whole
+        timelapse, in rank order, before the global flow solve. Blocks must have equal length."""
+        from .sharded import all_gather_detections
+        self.d_conf, self.d_x, self.d_y, self.d_count = all_gather_detections(
+            self.d_conf, self.d_x, self.d_y, self.d_count, group)
+        self._host, self._det_tables = None, None
 
     def _host_dets(self):
         """(count i32 [F], conf f32 [F,cap], x, y) on the host, fetched once."""
@@ -151,7 +162,7 @@ class AxonDetections(object):
         elif which_dets == 'confident':
             det = self._detections[t][self._detections[t].conf > self.conf_thr]
         elif which_dets == 'IDed':
-            assert getattr(self, '_IDed_detections', None), "Run .assign_IDs() first!"
+            assert self._IDed_detections, "Run .assign_IDs() first!"
             det = self._IDed_detections[t]
         else:
             raise NotImplementedError(f"which_dets={which_dets!r} needs labels (out of scope)")
@@ -173,12 +184,54 @@ class AxonDetections(object):
     # ------------------------------------------------------------------ association (AxonDetections.py:505-524)
     def assign_ids(self, astar_paths_cache=None, assigedIDs_cache=None):
         if assigedIDs_cache == 'from':
-            self._IDed_detections = self.from_cache('_IDed_detections')
+            self._set_ided_from_tables(self.from_cache('_IDed_detections'))
         else:
-            self._IDed_detections = self._assign_IDs_to_detections()
-            if assigedIDs_cache == 'to' and self._IDed_detections is not None:
+            self._solved = self._assign_IDs_to_detections()
+            self._ided_tables = None
+            if assigedIDs_cache == 'to' and self._solved:
                 self.to_cache('_IDed_detections', self._IDed_detections)
-        self.IDed_dets_all = self._agg_all_IDed_dets() if self._IDed_detections is not None else None
+        self.IDed_dets_all = self._agg_all_IDed_dets() if self._solved else None
+
+    @property
+    def _IDed_detections(self):
+        """list of per-frame DataFrames of the IDed detections, rows sorted by ID, index Axon_{id:03}
+        (libmot_det2det, AxonDetections.py:786-823); None if the flow problem was infeasible (:691-696).
+        Built on first access -- the hot path itself only keeps arrays."""
+        if not getattr(self, '_solved', False):
+            return None
+        if self._ided_tables is None:
+            cnt, conf, x, y = self._host_dets()
+            frame, tid, c, xx, yy = self.ided_arrays()
+            order = np.lexsort((tid, frame))
+            frame, tid, c, xx, yy = frame[order], tid[order], c[order], xx[order], yy[order]
+            bounds = np.searchsorted(frame, np.arange(len(cnt) + 1))
+            tabs = []
+            for f in range(len(cnt)):
+                lo, hi = bounds[f], bounds[f + 1]
+                if lo == hi:
+                    tabs.append(pd.DataFrame([]))          # "if frame empty, no detections" (:819-821)
+                    continue
+                tabs.append(pd.DataFrame({'conf': pd.array(c[lo:hi], dtype='Float32'),
+                                          'anchor_x': pd.array(xx[lo:hi].astype(np.int64), dtype='Int64'),
+                                          'anchor_y': pd.array(yy[lo:hi].astype(np.int64), dtype='Int64')},
+                                         index=[f'Axon_{i:0>3}' for i in tid[lo:hi]]))
+            self._ided_tables = tabs
+        return self._ided_tables
+
+    def _set_ided_from_tables(self, tables):
+        """Adopt reference-format per-frame IDed tables (the '_IDed_detections' cache)."""
+        cnt, conf, x, y = self._host_dets()
+        offs = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+        track = np.full(int(offs[-1]), -1, np.int32)
+        for f, t in enumerate(tables):
+            if len(t) == 0:
+                continue
+            tx, ty = t.anchor_x.to_numpy(dtype=np.int64), t.anchor_y.to_numpy(dtype=np.int64)
+            for name, ax, ay in zip(t.index, tx, ty):
+                k = np.nonzero((x[f, :cnt[f]] == ax) & (y[f, :cnt[f]] == ay))[0][0]   # exact anchor match (:804-808)
+                track[offs[f] + k] = int(name[-3:])
+        self._track_flat, self._offs = track, offs
+        self._solved, self._ided_tables = True, list(tables)
 
     def astar_dists(self):
         """_get_astar_path_distances(_compute_detections_astar_paths()) (AxonDetections.py:526-585,717-752):
@@ -209,12 +262,29 @@ class AxonDetections(object):
         return self._mask_t
 
     def _assign_IDs_to_detections(self):
-        """AxonDetections.py:631-715 with the tracker replaced by axt_build_arcs + axt_mcf_solve."""
+        """AxonDetections.py:631-715 with the tracker replaced by axt_build_arcs + axt_mcf_solve
+        (parameters['ASSOCIATION'] = 'mcf', the default and the reference's behaviour) or by the
+        frame-to-frame Hungarian variant of BASELINE config 3 ('hungarian')."""
         P = self.P
         if self.dataset.mask2d is not None:
             raise NotImplementedError('masked timelapses (A* on a non-trivial mask) are not built yet')
         table, dmax = transition_cost_table(P, self.max_px_assoc_dist)
         units = np.where(np.isfinite(table), np.rint(table * 1e6), 0).astype(np.int64)
+        mode = P.get('ASSOCIATION', 'mcf')
+        if mode == 'hungarian':
+            track, n_tracks = hp.hungarian_assoc(self.d_x, self.d_y, self.d_count, self.dataset.sizey,
+                                                 self.dataset.sizex, dmax, units,
+                                                 int(np.rint(P['MCF_EDGE_COST_THR'] * 1e6)),
+                                                 self.max_px_assoc_dist, self.conn8)
+            cnt = self._host_dets()[0]
+            track_h = track.cpu().numpy()
+            valid = np.arange(track_h.shape[1])[None, :] < cnt[:, None]
+            self._track_flat = track_h[valid]
+            self._offs = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+            self.n_ids, self.mcf_total_cost = int(n_tracks.item()), None
+            return True
+        if mode != 'mcf':
+            raise ValueError(f"parameters['ASSOCIATION'] must be 'mcf' or 'hungarian', got {mode!r}")
         obs = hp.obs_costs(self.d_conf, self.d_count, P['MCF_CONF_CAPPING_METHOD'], P['MCF_MAX_CONF_COST'])
         row_ptr, col, length, gap, cost = hp.build_arcs(self.d_x, self.d_y, self.d_count, self.dataset.sizey,
                                                         self.dataset.sizex, dmax, units, None,
@@ -236,29 +306,11 @@ class AxonDetections(object):
             print('Could not solve the graph for identity association; -> no IDed detections. Try narrowing '
                   'expected identities by updating parameters[`MCF_MIN_FLOW`, `MCF_MAX_FLOW`]. '
                   f"Currently: {P['MCF_MIN_FLOW']} to {P['MCF_MAX_FLOW']}.")
-            return None
+            return False
         nxt, track, n_tracks, total = res
         self.mcf_total_cost, self.n_ids = total, n_tracks
         self._track_flat, self._offs = track, offs
-        # per-frame tables, rows sorted by ID (libmot_det2det, AxonDetections.py:786-823)
-        frame_of = np.repeat(np.arange(len(cnt)), cnt)
-        idx_in = k - offs[frame_of]
-        sel = track >= 0
-        tabs = []
-        order = np.lexsort((track[sel], frame_of[sel]))
-        f_s, id_s, i_s = frame_of[sel][order], track[sel][order], idx_in[sel][order]
-        bounds = np.searchsorted(f_s, np.arange(len(cnt) + 1))
-        for f in range(len(cnt)):
-            lo, hi = bounds[f], bounds[f + 1]
-            if lo == hi:
-                tabs.append(pd.DataFrame([]))
-                continue
-            ii = i_s[lo:hi]
-            tabs.append(pd.DataFrame({'conf': pd.array(conf[f, ii], dtype='Float32'),
-                                      'anchor_x': pd.array(x[f, ii].astype(np.int64), dtype='Int64'),
-                                      'anchor_y': pd.array(y[f, ii].astype(np.int64), dtype='Int64')},
-                                     index=[f'Axon_{i:0>3}' for i in id_s[lo:hi]]))
-        return tabs
+        return True
 
     def ided_arrays(self):
         """(frame i32, id i32, conf f32, x i32, y i32) of every IDed detection, frame-major."""

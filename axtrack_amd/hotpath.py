@@ -69,6 +69,24 @@ class Detector:
     def device_bytes(self):
         return int(self._lib.axt_detector_device_bytes(self._h))
 
+    KERNEL_NAMES = ['conv0 5>20 s2', 'conv1 20>40 s2', 'conv2 40>80 +pool', 'conv4 80>80', 'conv5 80>80 +pool',
+                    'conv7 80>80', 'conv8 80>80 +pool', 'conv10 80>160', 'fc1 gemm', 'fc1 reduce', 'fc2 gemm',
+                    'fc2 reduce', 'fc3 gemm', 'fc3 reduce']
+
+    def set_profiling(self, on):
+        _lib.check(self._lib.axt_detector_set_profiling(self._h, int(bool(on))), 'axt_detector_set_profiling')
+
+    def read_profile(self):
+        """Per-kernel HIP-event times since the last read: list of dicts (name, ms, launches, tiles, flops_per_tile)."""
+        n = len(self.KERNEL_NAMES)
+        ms = np.zeros(n, np.float64)
+        launches = np.zeros(n, np.int64)
+        items = np.zeros(n, np.int64)
+        _lib.check(self._lib.axt_detector_read_profile(self._h, ms.ctypes.data, launches.ctypes.data,
+                                                       items.ctypes.data, n), 'axt_detector_read_profile')
+        return [dict(name=self.KERNEL_NAMES[i], ms=float(ms[i]), launches=int(launches[i]), tiles=int(items[i]),
+                     flops_per_tile=float(self._lib.axt_cnn_kernel_flops_per_tile(i))) for i in range(n)]
+
     def eval(self):
         return self
 
@@ -196,6 +214,26 @@ def build_arcs(x, y, count, H, W, dmax, cost_units=None, mask=None, max_dist=MAX
                                       _lib.dptr(cost), ctypes.byref(n_arcs), _stream()), 'axt_build_arcs(fill)')
     n = int(n_arcs.value)
     return row_ptr, col[:n], length[:n], gap[:n], (cost[:n] if cost is not None else None)
+
+
+def hungarian_assoc(x, y, count, H, W, dmax, cost_units, thr_units, max_dist=MAX_PX_ASSOC_DIST, conn8=False):
+    """Frame-to-frame Hungarian association (BASELINE config 3) of a whole timelapse on the GPU.
+    Returns (track i32 [F,cap] device tensor, n_tracks device tensor [1])."""
+    n_frames, cap = x.shape
+    max_gap = len(dmax)
+    dev = x.device
+    h_dmax = np.ascontiguousarray(dmax, np.int32)
+    cu = torch.as_tensor(np.ascontiguousarray(cost_units, np.int64)).to(dev)
+    work = torch.empty((4 * n_frames * cap + n_frames + 1,), dtype=torch.int32, device=dev)
+    track = torch.empty((n_frames, cap), dtype=torch.int32, device=dev)
+    n_tracks = torch.zeros((1,), dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        _lib.check(lib.axt_hungarian_assoc(x.data_ptr(), y.data_ptr(), count.data_ptr(), n_frames, cap, H, W,
+                                           int(max_dist), int(bool(conn8)), max_gap, h_dmax.ctypes.data,
+                                           cu.data_ptr(), int(thr_units), work.data_ptr(), track.data_ptr(),
+                                           n_tracks.data_ptr(), _stream()), 'axt_hungarian_assoc')
+    return track, n_tracks
 
 
 def arc_cost_int(cost, kind, a, b):

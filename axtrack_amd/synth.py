@@ -43,8 +43,10 @@ def normal(seed, shape):
     return z.reshape(shape)
 
 
-def synth_frames(T_all, H, W, seed=0, n_blobs=None, bg_frac=0.02):
+def synth_frames(T_all, H, W, seed=0, n_blobs=None, bg_frac=0.02, t_range=None):
     """Preprocessed-looking timelapse, f32 [T_all, H, W].
+    t_range=(a, b) renders only frames a..b-1 of that timelapse (frame-sharded ranks), identical
+    to slicing the full result.
 
     ~bg_frac of the pixels carry background speckle in (0, 3]; `n_blobs` Gaussian blobs
     (sigma 4 px, peak ~8) random-walk <= 10 px/frame as growth cones. Every 512x512 tile is
@@ -53,20 +55,23 @@ def synth_frames(T_all, H, W, seed=0, n_blobs=None, bg_frac=0.02):
     """
     if n_blobs is None:
         n_blobs = max(8, (H * W) // 5243)          # ~50 per 512x512
-    frames = np.zeros((T_all, H, W), np.float32)
+    ta, tb = (0, T_all) if t_range is None else t_range
+    frames = np.zeros((tb - ta, H, W), np.float32)
     # background speckle, different every frame
-    for t in range(T_all):
+    for t in range(ta, tb):
         u = uniform01(seed * 1000003 + 17 * t + 1, (H, W))
         v = uniform01(seed * 1000003 + 17 * t + 2, (H, W))
-        frames[t] = np.where(u < bg_frac, (0.2 + 2.8 * v), 0.0).astype(np.float32)
+        frames[t - ta] = np.where(u < bg_frac, (0.2 + 2.8 * v), 0.0).astype(np.float32)
     # blobs
     pos = uniform01(seed * 7919 + 3, (n_blobs, 2)) * np.array([H - 1, W - 1])
     steps = (uniform01(seed * 7919 + 4, (T_all, n_blobs, 2)) * 2.0 - 1.0) * 10.0
     amp = 4.0 + 6.0 * uniform01(seed * 7919 + 5, (n_blobs,))
     r = 12
     yy, xx = np.mgrid[-r:r + 1, -r:r + 1]
-    for t in range(T_all):
+    for t in range(tb):
         pos = np.clip(pos + steps[t], 0, [H - 1, W - 1])
+        if t < ta:
+            continue
         for b in range(n_blobs):
             cy, cx = int(round(pos[b, 0])), int(round(pos[b, 1]))
             g = (amp[b] * np.exp(-(yy ** 2 + xx ** 2) / (2 * 4.0 ** 2))).astype(np.float32)
@@ -74,7 +79,7 @@ def synth_frames(T_all, H, W, seed=0, n_blobs=None, bg_frac=0.02):
             y0, y1 = max(cy - r, 0), min(cy + r + 1, H)
             x0, x1 = max(cx - r, 0), min(cx + r + 1, W)
             sub = g[y0 - (cy - r):y1 - (cy - r), x0 - (cx - r):x1 - (cx - r)]
-            frames[t, y0:y1, x0:x1] = np.maximum(frames[t, y0:y1, x0:x1], sub)
+            frames[t - ta, y0:y1, x0:x1] = np.maximum(frames[t - ta, y0:y1, x0:x1], sub)
     return frames
 
 

@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec of AxTrack's detect + associate hot path on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path (axtrack_amd.inference: tile occupancy -> CNN forward ->
+decode/stitch/NMS -> [all-gather] -> arcs + observation costs -> min-cost-flow -> IDed_dets_all)
+over a synthetic 512x512 timelapse that is already resident in HBM. Default workload is BASELINE
+config "c3" (512x512x256, detection + association); "c2" is detection only.
+
+Multi-GPU (weak scaling): the timelapse has N x 252 detection frames, rank r detects its own
+contiguous block (reading a 2-frame halo), ONE all-gather of the detection lists over RCCL, then
+every rank runs the same deterministic global solve (replicated).
+
+Prints ONE JSON line on rank 0 (contract: see the task description), with
+  roofline     -- dominant kernel: algorithmic FLOPs / HIP-event time measured inside the timed
+                  region on the launch stream, against the f32 MFMA peak (157.3 TFLOP/s);
+  cpu_baseline -- the CPU oracle (a port of the reference's algorithm, oracle/) timed on this
+                  box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', default='c3', choices=['c2', 'c3'])
+    ap.add_argument('--assoc', default='hungarian', choices=['hungarian', 'mcf'],
+                    help="association of workload c3: 'hungarian' = BASELINE config 3 as written (frame-to-frame), "
+                         "'mcf' = the reference's global min-cost-flow tracker")
+    ap.add_argument('--frames', type=int, default=256, help='input frames per GPU (T_all)')
+    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--cpu-frames', type=int, default=24, help='detection frames of the CPU-baseline sample (0 = skip)')
+    ap.add_argument('--no-profile', action='store_true', help='do not bracket kernels with HIP events')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+
+    import axtrack_amd
+    from axtrack_amd import synth, params
+
+    H = W = args.size
+    per_rank = args.frames - 4                      # detection frames per GPU
+    total_frames = per_rank * world
+    T_all_global = total_frames + 4
+    # this rank's block of the global timelapse, with its 2-frame halo on both sides
+    f0 = rank * per_rank
+    frames = synth.synth_frames(T_all_global, H, W, seed=0, t_range=(f0, f0 + per_rank + 4))
+    sd = synth.synth_state_dict(42)
+    P = params.load_parameters()
+    P['DEVICE'] = str(dev)
+    P['ASSOCIATION'] = args.assoc
+    n_tiles = (-(-H // 512)) * (-(-W // 512))
+    model = axtrack_amd.Detector(sd, max_batch=min(per_rank * n_tiles, 1024), device=dev)
+    tl = axtrack_amd.Timelapse(frames, name='bench', device=dev)
+    del frames
+
+    def step():
+        ad = axtrack_amd.AxonDetections(model, tl, P, None)
+        ad.detect_dataset(cache=None)
+        if args.workload == 'c3':
+            if world > 1:
+                ad.gather_detections()
+            ad.assign_ids(None, None)
+        return ad
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        ad = step()
+    sync_all()
+    if not args.no_profile:
+        model.set_profiling(True)
+        model.read_profile()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ad = step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    prof = None
+    if not args.no_profile:
+        prof = model.read_profile()
+        model.set_profiling(False)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    # ---- stage breakdown (one extra, untimed, synchronised step on rank 0's clock)
+    stages = {}
+    def timed(name, fn):
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize(dev)
+        stages[name] = round((time.perf_counter() - t) * 1e3, 3)
+        return r
+    ad2 = axtrack_amd.AxonDetections(model, tl, P, None)
+    timed('detect_ms', lambda: ad2.detect_dataset(cache=None))
+    if args.workload == 'c3':
+        if world > 1:
+            timed('allgather_ms', ad2.gather_detections)
+        timed('associate_ms', lambda: ad2.assign_ids(None, None))
+
+    # the other association variant, measured in the same run (untimed region, one step) for transparency
+    other = None
+    if args.workload == 'c3' and world == 1:
+        P2 = dict(P, ASSOCIATION='mcf' if args.assoc == 'hungarian' else 'hungarian')
+        ad3 = axtrack_amd.AxonDetections(model, tl, P2, None)
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        ad3.detect_dataset(cache=None)
+        ad3.assign_ids(None, None)
+        torch.cuda.synchronize(dev)
+        dt3 = time.perf_counter() - t
+        other = {'association': P2['ASSOCIATION'], 'value': round(total_frames / dt3, 2), 'unit': 'frames/s',
+                 'ms_per_step': round(dt3 * 1e3, 3), 'n_ids': ad3.n_ids, 'steps': 1}
+
+    if rank == 0:
+        value = total_frames * args.steps / dt
+        out = {
+            'metric': 'frames/sec end-to-end detect+associate, 512x512xT timelapse' if args.workload == 'c3'
+                      else 'frames/sec detection only (CNN forward + NMS), 512x512xT timelapse',
+            'value': round(value, 2), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{args.workload}: synthetic {H}x{W}x{args.frames} grayscale timelapse per GPU, '
+                                   + (f'detection + path-cost matrix + {"Hungarian (frame-to-frame)" if args.assoc == "hungarian" else "global min-cost-flow"} association (IDed_dets_all)'
+                                      if args.workload == 'c3' else 'detection only'),
+                       'association': args.assoc if args.workload == 'c3' else None,
+                       'detection_frames_per_gpu': per_rank, 'tiles_per_frame': n_tiles,
+                       'weights': 'random-init (synth seed 42)', 'parallelism': f'frame-sharded x{world}'},
+            'stages': stages,
+            'detections': int(ad._host_dets()[0].sum()),
+        }
+        if args.workload == 'c3':
+            out['n_ids'] = getattr(ad, 'n_ids', None)
+            if other:
+                out['other_association_variant'] = other
+        if prof:
+            dom = max(prof, key=lambda k: k['ms'])
+            flops = dom['flops_per_tile'] * dom['tiles']
+            achieved = flops / (dom['ms'] * 1e-3) / 1e12
+            cnn_ms = sum(k['ms'] for k in prof)
+            cnn_flops = sum(k['flops_per_tile'] * k['tiles'] for k in prof if 'reduce' not in k['name'])
+            out['roofline'] = {
+                'bound': 'mfma', 'kernel': dom['name'], 'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
+                'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                'avg_launch_ms': round(dom['ms'] / max(dom['launches'], 1), 4),
+                'flops_per_launch': flops / max(dom['launches'], 1),
+                'whole_cnn': {'achieved': round(cnn_flops / (cnn_ms * 1e-3) / 1e12, 2),
+                              'frac': round(cnn_flops / (cnn_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                              'ms_per_step': round(cnn_ms / args.steps, 3)},
+                'kernels': [{'name': k['name'], 'ms_per_step': round(k['ms'] / args.steps, 4),
+                             'tflops': round(k['flops_per_tile'] * k['tiles'] / max(k['ms'], 1e-9) / 1e9, 2)}
+                            for k in prof],
+            }
+        if world == 1 and args.cpu_frames > 0:
+            out['cpu_baseline'] = cpu_baseline(args, sd, synth)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, sd, synth):
+    """The CPU oracle on the first `cpu_frames` detection frames of the same timelapse."""
+    from oracle import oracle as orc
+    n = args.cpu_frames
+    cores = min(len(os.sched_getaffinity(0)), 16)          # a one-GPU box's CPU share
+    os.environ['OMP_NUM_THREADS'] = str(cores)
+    frames = synth.synth_frames(args.frames, args.size, args.size, seed=0, t_range=(0, n + 4))
+    Pc = dict(orc.DEFAULTS, MCF_MIN_FLOW=1)
+    t = time.perf_counter()
+    if args.workload == 'c3':
+        orc.inference(frames, sd, P=Pc, assoc=args.assoc)
+    else:
+        orc.detect_dataset(frames, sd)
+    dt = time.perf_counter() - t
+    return {'value': round(n / dt, 3), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+            'sample': f'first {n} detection frames of the same synthetic timelapse ({dt:.1f} s of CPU work), '
+                      f'oracle/ (C + numpy restatement, OpenMP x{cores})'}
+
+
+if __name__ == '__main__':
+    main()

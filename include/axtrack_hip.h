@@ -78,8 +78,18 @@ int axt_cnn_forward_frames(axt_detector *det, const float *d_frames, int T_all, 
                            int t0, int n_frames, const int32_t *h_tile_yx, int n_tiles,
                            float *d_yolo, void *stream);
 
-/* FLOPs of one tile-forward as executed (algorithmic: 2*M*N*K of the unpadded layers). */
+/* FLOPs of one tile-forward (algorithmic: 2*M*N*K of the unpadded layers). */
 double axt_cnn_flops_per_tile(void);
+
+/* Per-kernel timing for the roofline report (bench.py): when on, every kernel launch of the
+ * forward pass is bracketed by HIP events on the launch stream. Kernel ids: 0..7 the eight conv
+ * blocks, 8/10/12 the linear-layer GEMMs, 9/11/13 their split-K reductions.
+ * axt_detector_read_profile synchronises on the recorded events and returns, per kernel id, the
+ * summed milliseconds, the number of launches and the number of tile-forwards since the last read. */
+#define AXT_N_CNN_KERNELS 14
+int axt_detector_set_profiling(axt_detector *det, int on);
+int axt_detector_read_profile(axt_detector *det, double *ms, int64_t *launches, int64_t *items, int n);
+double axt_cnn_kernel_flops_per_tile(int kernel);
 
 /* ------------------------------------------------------------------------------------------
  * Tiling: which 512x512 tiles the reference keeps (Timelapse.py:551-558): a tile is kept if
@@ -159,6 +169,22 @@ int axt_mcf_solve(int n_det, const int64_t *h_obs, const int64_t *h_entry, const
                   const int64_t *h_row_ptr, const int32_t *h_col, const int64_t *h_cost,
                   int min_flow, int max_flow,
                   int32_t *h_next, int32_t *h_track, int *n_tracks, int64_t *total_cost);
+
+/* ------------------------------------------------------------------------------------------
+ * Frame-to-frame Hungarian association (BASELINE config 3; a build-side variant -- the reference
+ * only runs the global tracker above). Same cost model: linking a (frame t) to b (frame t+g)
+ * costs transition_model(D(a,b), g) and is admitted for D <= h_dmax[g-1]; leaving a detection
+ * without successor costs thr_units (= round(MCF_EDGE_COST_THR * 1e6)). Every frame pair
+ * (t,t+1) is solved exactly and independently (one wavefront each), then (t,t+2) among the
+ * detections left unlinked, then chains are numbered by (first frame, index).
+ * d_cost_units i64 [max_gap, max_dist+1]; d_work i32 [4*n_frames*cap + n_frames + 1] scratch;
+ * d_track i32 [n_frames, cap]: trajectory id of every detection slot (-1 beyond count);
+ * d_n_tracks i32 [1]. All-ones mask only (closed-form path lengths). Asynchronous.
+ * ------------------------------------------------------------------------------------------ */
+int axt_hungarian_assoc(const int32_t *d_x, const int32_t *d_y, const int32_t *d_count, int n_frames, int cap,
+                        int H, int W, int max_dist, int conn8, int max_gap, const int32_t *h_dmax,
+                        const int64_t *d_cost_units, int64_t thr_units, int32_t *d_work,
+                        int32_t *d_track, int32_t *d_n_tracks, void *stream);
 
 /* Integer arc cost used by the flow network: round(cost * 1e6) << 16 | hash16(kind, a, b).
  * kind 0 entry, 1 exit, 2 observation, 3 transition. The low 16 bits make the optimum unique

@@ -355,6 +355,70 @@ def mcf_solve(dets, D, P=DEFAULTS, name='synth'):
     return trajs, int(tot.value)
 
 
+# ------------------------------------------------------------------------------- config 3 variant
+def hungarian_assoc(dets, H, W, P=DEFAULTS, mask=None):
+    """Frame-to-frame Hungarian association (BASELINE config 3; the reference has no such code,
+    SURVEY.md F7 -- this is the build's own definition, solved here with SciPy's
+    linear_sum_assignment as the independent exact solver).
+
+    Pass 1, every pair (t, t+1): rows = detections of t, columns = detections of t+1 plus one
+    private "no successor" column per row; cost = integer transition cost (arc_cost_int kind 3) where
+    transition_cost < MCF_EDGE_COST_THR, forbidden otherwise; the private column costs
+    arc_cost_int(THR, 1, a, 0). Pass 2, pairs (t, t+2), restricted to rows without successor and
+    columns without predecessor after pass 1. Chains are numbered by (first frame, index).
+    Returns the list of trajectories [(frame, idx), ...] in id order."""
+    from scipy.optimize import linear_sum_assignment
+    counts = [len(d[0]) for d in dets]
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    F = len(dets)
+    thr = P['MCF_EDGE_COST_THR']
+    succ = [np.full(n, -1, np.int64) for n in counts]       # (frame offset encoded separately)
+    succ_gap = [np.zeros(n, np.int64) for n in counts]
+    has_pred = [np.zeros(n, bool) for n in counts]
+
+    def solve(t, gap, rows, cols):
+        tb = t + gap
+        if len(rows) == 0:
+            return
+        sub_s = tuple(a[rows] for a in dets[t])
+        sub_d = tuple(a[cols] for a in dets[tb])
+        D = path_matrix(sub_s, sub_d, H, W, mask) if len(cols) else np.zeros((len(rows), 0), np.int32)
+        c = transition_cost(D, gap, P['MCF_MISS_RATE'])
+        n, m = len(rows), len(cols)
+        M = np.full((n, m + n), np.inf)
+        for i in range(n):
+            a = int(offs[t] + rows[i])
+            for j in np.nonzero(c[i] < thr)[0]:
+                M[i, j] = float(arc_cost_int(c[i, j], 3, a, int(offs[tb] + cols[j])))
+            M[i, m + i] = float(arc_cost_int(thr, 1, a, 0))
+        ri, ci = linear_sum_assignment(M)
+        for i, j in zip(ri, ci):
+            if j < m:
+                succ[t][rows[i]] = cols[j]
+                succ_gap[t][rows[i]] = gap
+                has_pred[tb][cols[j]] = True
+
+    for t in range(F - 1):
+        solve(t, 1, np.arange(counts[t]), np.arange(counts[t + 1]))
+    if P['MCF_MAX_NUM_MISSES'] >= 1:
+        pred1 = [h.copy() for h in has_pred]
+        for t in range(F - 2):
+            solve(t, 2, np.nonzero(succ[t] < 0)[0], np.nonzero(~pred1[t + 2])[0])
+    trajs = []
+    for t in range(F):
+        for i in range(counts[t]):
+            if has_pred[t][i]:
+                continue
+            tr, f, k = [], t, i
+            while True:
+                tr.append((f, int(k)))
+                if succ[f][k] < 0:
+                    break
+                f, k = f + int(succ_gap[f][k]), succ[f][k]
+            trajs.append(tr)
+    return trajs
+
+
 # ------------------------------------------------------------------------------- a-13
 def ided_tables(trajs, dets):
     """:699-711 + libmot_det2det (:786-823): per frame, rows (id, conf, x, y) sorted by id.
@@ -395,13 +459,19 @@ def ided_dets_all(tables, reproduce_label_quirk=True):
 
 
 # ------------------------------------------------------------------------------- whole path
-def inference(frames, sd, mask=None, P=DEFAULTS, name='synth', yolo=None):
-    """interface.inference (interface.py:170-215): detect_dataset + assign_ids."""
+def inference(frames, sd, mask=None, P=DEFAULTS, name='synth', yolo=None, assoc='mcf'):
+    """interface.inference (interface.py:170-215): detect_dataset + assign_ids.
+    assoc='mcf' is the reference's global tracker; 'hungarian' the BASELINE config 3 variant."""
     keep = kept_tiles(frames, P['TILESIZE'])
     if yolo is None:
         dets, yolo = detect_dataset(frames, sd, P['TILESIZE'], P['NON_MAX_SUPRESSION_DIST'], return_yolo=True)
     else:
         dets = detect_from_yolo(yolo, keep, P['TILESIZE'], P['NON_MAX_SUPRESSION_DIST'])
+    if assoc == 'hungarian':
+        trajs = hungarian_assoc(dets, frames.shape[1], frames.shape[2], P, mask)
+        tables = ided_tables(trajs, dets)
+        return dict(dets=dets, yolo=yolo, D=None, trajs=trajs, total_cost=None, tables=tables,
+                    ided_all=ided_dets_all(tables))
     D = all_path_matrices(dets, frames.shape[1], frames.shape[2], mask, P['MCF_MAX_NUM_MISSES'], name)
     trajs, total = mcf_solve(dets, D, P, name)
     tables = ided_tables(trajs, dets) if trajs else None

@@ -282,3 +282,66 @@ def test_full_size_properties_c3(weights):
     ad2 = _run_inference(frames, weights, P, name='c3')
     assert np.array_equal(ad2._track_flat, ad._track_flat) and ad2.mcf_total_cost == ad.mcf_total_cost
     assert torch.equal(ad2._yolo, ad._yolo)
+
+
+# ----------------------------------------------------------------------------------------- config 3 variant
+def _hungarian_tracks(dets, H, W):
+    from axtrack_amd.detections import transition_cost_table
+    F = len(dets)
+    cap = max(len(d[0]) for d in dets) + 3
+    x = np.zeros((F, cap), np.int32); y = np.zeros((F, cap), np.int32)
+    for t, d in enumerate(dets):
+        x[t, :len(d[1])] = d[1]; y[t, :len(d[2])] = d[2]
+    cnt = np.array([len(d[0]) for d in dets], np.int32)
+    table, dmax = transition_cost_table(params.DEPLOYED)
+    units = np.where(np.isfinite(table), np.rint(table * 1e6), 0).astype(np.int64)
+    track, n_tracks = hp.hungarian_assoc(dev(x), dev(y), dev(cnt), H, W, dmax, units, 700000)
+    track = track.cpu().numpy()
+    offs = np.concatenate([[0], np.cumsum(cnt)])
+    flat = np.concatenate([track[t, :cnt[t]] for t in range(F)])
+    assert (track[np.arange(cap)[None, :] >= cnt[:, None]] == -1).all()
+    return tracks_from_next(np.zeros(len(flat)), flat, offs), int(n_tracks.item())
+
+
+def test_hungarian_association_matches_scipy_oracle(golden):
+    g = golden('detect_1024')
+    dets = golden_dets(g)
+    got, n = _hungarian_tracks(dets, 1024, 1024)
+    ref = orc.hungarian_assoc(dets, 1024, 1024)
+    assert n == len(ref) and got == ref
+
+
+@pytest.mark.parametrize('seed', range(4))
+def test_hungarian_association_random_frames(seed):
+    """Crowded random frames with detections appearing/disappearing: contested columns, gap-2 links,
+    empty frames."""
+    rng = np.random.default_rng(100 + seed)
+    F = 7
+    dets = []
+    for t in range(F):
+        n = 0 if (seed == 3 and t == 3) else int(rng.integers(1, 60))
+        conf = np.sort(rng.uniform(0.55, 1.2, n).astype(np.float32))[::-1]
+        dets.append((conf, rng.integers(-5, 300, n), rng.integers(0, 300, n)))
+    got, n = _hungarian_tracks(dets, 300, 300)
+    ref = orc.hungarian_assoc(dets, 300, 300)
+    assert n == len(ref) and got == ref
+
+
+def test_inference_hungarian_mode_end_to_end(weights):
+    frames = synth.synth_frames(10, 512, 512, seed=21)
+    P = params.load_parameters()
+    P['ASSOCIATION'] = 'hungarian'
+    ad = _run_inference(frames, weights, P)
+    yolo = ad._yolo.cpu().numpy()
+    ref = orc.inference(frames, weights, P=orc.DEFAULTS, yolo=list(yolo), assoc='hungarian')
+    got = tracks_from_next(np.zeros(len(ad._track_flat)), ad._track_flat, ad._offs)
+    assert got == ref['trajs'] and ad.n_ids == len(ref['trajs'])
+    ids, labels, info, vals = ref['ided_all']
+    df = ad.IDed_dets_all
+    assert list(df.index) == [f'Axon_{i:0>3}' for i in ids]
+    assert np.array_equal(np.nan_to_num(df.to_numpy(), nan=-1), np.nan_to_num(vals, nan=-1))
+    # per-frame IDed tables (built lazily) carry the same rows
+    tabs = ad._IDed_detections
+    for f, rows in enumerate(ref['tables']):
+        assert [int(n[-3:]) for n in tabs[f].index] == [r[0] for r in rows]
+        assert list(tabs[f].anchor_x) == [r[2] for r in rows]
