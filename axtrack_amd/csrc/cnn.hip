@@ -133,26 +133,57 @@ __global__ __launch_bounds__(256) void conv3x3_mfma(
     const int b_base = q * NPADW + p;
     const float *wsrc = wpk + (long)grp * NCHUNK * KROWS * NPADW;
 
+    // ---- staging plan: every thread moves NPE patch elements and NWE float4 of weights per chunk.
+    // Their positions do not depend on the chunk, so the index arithmetic is done once; per chunk all
+    // loads are issued back to back into registers (no wait in between) and written to LDS after the
+    // barrier, while the next chunk's loads are already in flight behind the MFMAs.
+    constexpr int NPC = FIRST ? CIN : CCH;
+    constexpr int NPE = (NPC * PH * PW + 255) / 256;
+    constexpr int NW4 = KROWS * NPADW / 4;
+    constexpr int NWE = (NW4 + 255) / 256;
+    int goff[NPE], loff[NPE];            // global offset inside the chunk (-1: zero padding), LDS offset (-1: none)
+#pragma unroll
+    for (int k = 0; k < NPE; ++k) {
+        const int e = tid + k * 256;
+        const int c = e / (PH * PW), rem = e - c * (PH * PW);
+        const int r = rem / PW, col = rem - r * PW;
+        const int gy = iy0 + r, gx = ix0 + col;
+        const bool in_patch = e < NPC * PH * PW;
+        const bool in_img = in_patch && gy >= 0 && gy < lim_y && gx >= 0 && gx < lim_x;
+        loff[k] = in_patch ? c * PLANE + r * PW + col : -1;
+        goff[k] = in_img ? (int)(c * cstride + (long)gy * rstride + gx) : -1;
+    }
+    float pv[NPE];
+    f32x4 wv[NWE];
+    auto load_chunk = [&](int chunk) {
+        const float *csrc = src + (long)chunk * CCH * cstride;
+#pragma unroll
+        for (int k = 0; k < NPE; ++k) pv[k] = goff[k] >= 0 ? csrc[goff[k]] : 0.f;
+        const f32x4 *w4 = reinterpret_cast<const f32x4 *>(wsrc + (long)chunk * KROWS * NPADW);
+#pragma unroll
+        for (int k = 0; k < NWE; ++k) {
+            const int e = tid + k * 256;
+            wv[k] = (NW4 % 256 == 0 || e < NW4) ? w4[e] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int k = 0; k < NPE; ++k)
+            if (loff[k] >= 0) patch[loff[k]] = pv[k];
+        f32x4 *l4 = reinterpret_cast<f32x4 *>(wl);
+#pragma unroll
+        for (int k = 0; k < NWE; ++k) {
+            const int e = tid + k * 256;
+            if (NW4 % 256 == 0 || e < NW4) l4[e] = wv[k];
+        }
+    };
+
+    load_chunk(0);
     for (int chunk = 0; chunk < NCHUNK; ++chunk) {
-        if (chunk) __syncthreads();
-        // ---- stage the input patch: CCH (FIRST: 5) channels x PH x PW, zero outside the image
-        constexpr int NPC = FIRST ? CIN : CCH;
-        for (int e = tid; e < NPC * PH * PW; e += 256) {
-            const int c = e / (PH * PW), rem = e - c * (PH * PW);
-            const int r = rem / PW, col = rem - r * PW;
-            const int gy = iy0 + r, gx = ix0 + col;
-            float v = 0.f;
-            if (gy >= 0 && gy < lim_y && gx >= 0 && gx < lim_x)
-                v = src[(long)(chunk * CCH + c) * cstride + (long)gy * rstride + gx];
-            patch[c * PLANE + r * PW + col] = v;
-        }
-        // ---- stage this chunk's weights (contiguous, 16 B per lane)
-        {
-            const f32x4 *w4 = reinterpret_cast<const f32x4 *>(wsrc + (long)chunk * KROWS * NPADW);
-            f32x4 *l4 = reinterpret_cast<f32x4 *>(wl);
-            for (int e = tid; e < KROWS * NPADW / 4; e += 256) l4[e] = w4[e];
-        }
+        if (chunk) __syncthreads();          // every wave is done reading the previous chunk
+        store_chunk();
         __syncthreads();
+        if (chunk + 1 < NCHUNK) load_chunk(chunk + 1);
 
         // ---- MFMA over the chunk
 #pragma unroll
