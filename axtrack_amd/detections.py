@@ -266,12 +266,13 @@ class AxonDetections(object):
         (parameters['ASSOCIATION'] = 'mcf', the default and the reference's behaviour) or by the
         frame-to-frame Hungarian variant of BASELINE config 3 ('hungarian')."""
         P = self.P
-        if self.dataset.mask2d is not None:
-            raise NotImplementedError('masked timelapses (A* on a non-trivial mask) are not built yet')
         table, dmax = transition_cost_table(P, self.max_px_assoc_dist)
         units = np.where(np.isfinite(table), np.rint(table * 1e6), 0).astype(np.int64)
         mode = P.get('ASSOCIATION', 'mcf')
+        masked = self.dataset.mask2d is not None
         if mode == 'hungarian':
+            if masked:
+                raise NotImplementedError("ASSOCIATION='hungarian' supports all-ones masks only; use 'mcf'")
             track, n_tracks = hp.hungarian_assoc(self.d_x, self.d_y, self.d_count, self.dataset.sizey,
                                                  self.dataset.sizex, dmax, units,
                                                  int(np.rint(P['MCF_EDGE_COST_THR'] * 1e6)),
@@ -286,9 +287,12 @@ class AxonDetections(object):
         if mode != 'mcf':
             raise ValueError(f"parameters['ASSOCIATION'] must be 'mcf' or 'hungarian', got {mode!r}")
         obs = hp.obs_costs(self.d_conf, self.d_count, P['MCF_CONF_CAPPING_METHOD'], P['MCF_MAX_CONF_COST'])
-        row_ptr, col, length, gap, cost = hp.build_arcs(self.d_x, self.d_y, self.d_count, self.dataset.sizey,
-                                                        self.dataset.sizex, dmax, units, None,
-                                                        self.max_px_assoc_dist, self.conn8)
+        if masked:
+            row_ptr, col, cost = self._masked_arcs(dmax, units)
+        else:
+            row_ptr, col, length, gap, cost = hp.build_arcs(self.d_x, self.d_y, self.d_count, self.dataset.sizey,
+                                                            self.dataset.sizex, dmax, units, None,
+                                                            self.max_px_assoc_dist, self.conn8)
         cnt, conf, x, y = self._host_dets()
         offs = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
         n_det = int(offs[-1])
@@ -311,6 +315,41 @@ class AxonDetections(object):
         self.mcf_total_cost, self.n_ids = total, n_tracks
         self._track_flat, self._offs = track, offs
         return True
+
+    def _masked_arcs(self, dmax, units):
+        """Admissible arcs on a masked grid: one single-source path search per detection and frame pair
+        (axt_path_cost with the mask), thresholded and packed into the CSR layout of axt_build_arcs
+        (rows by tail detection, sorted by (gap, head)). Correct but not yet fused into one kernel."""
+        cnt = self._host_dets()[0]
+        offs = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+        n_det = int(offs[-1])
+        mask = self._mask_dev()
+        dev = self.device
+        units_d = torch.as_tensor(units).to(dev)
+        tails, heads, gaps, costs = [], [], [], []
+        for t in range(len(cnt)):
+            for g in range(1, len(dmax) + 1):
+                tb = t + g
+                if tb >= len(cnt) or cnt[t] == 0 or cnt[tb] == 0:
+                    continue
+                na, nb = int(cnt[t]), int(cnt[tb])
+                D = hp.path_cost(self.d_x[t, :na], self.d_y[t, :na], self.d_x[tb, :nb], self.d_y[tb, :nb],
+                                 self.dataset.sizey, self.dataset.sizex, mask, self.max_px_assoc_dist, self.conn8)
+                ij = torch.nonzero(D <= int(dmax[g - 1]))
+                if ij.numel() == 0:
+                    continue
+                a = ij[:, 0] + int(offs[t]); b = ij[:, 1] + int(offs[tb])
+                tails.append(a); heads.append(b); gaps.append(torch.full_like(a, g))
+                costs.append(_arc_cost_int_torch(units_d[g - 1][D[ij[:, 0], ij[:, 1]].long()], 3, a, b))
+        if not tails:
+            return torch.zeros(n_det + 1, dtype=torch.int64, device=dev), torch.zeros(0, dtype=torch.int32, device=dev), \
+                torch.zeros(0, dtype=torch.int64, device=dev)
+        a, b, g, c = torch.cat(tails), torch.cat(heads), torch.cat(gaps), torch.cat(costs)
+        order = torch.argsort((a * 16 + g) * (n_det + 1) + b)
+        a, b, c = a[order], b[order], c[order]
+        row_ptr = torch.zeros(n_det + 1, dtype=torch.int64, device=dev)
+        row_ptr[1:] = torch.cumsum(torch.bincount(a, minlength=n_det), 0)
+        return row_ptr, b.to(torch.int32), c
 
     def ided_arrays(self):
         """(frame i32, id i32, conf f32, x i32, y i32) of every IDed detection, frame-major."""
@@ -351,6 +390,24 @@ def _splitmix64(x):
     x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
     x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
     return x ^ (x >> np.uint64(31))
+
+
+def _lsr(x, s):
+    """logical right shift of an int64 tensor holding uint64 bits"""
+    return (x >> s) & ((1 << (64 - s)) - 1)
+
+
+def _arc_cost_int_torch(units, kind, a, b):
+    """axt_arc_cost_int on int64 device tensors (units = round(cost*1e6) already)."""
+    def s64(v):                                   # python int -> signed 64-bit two's complement
+        v &= 0xFFFFFFFFFFFFFFFF
+        return v - (1 << 64) if v >= (1 << 63) else v
+    x = (a << 30) ^ b ^ s64(kind << 60)
+    x = x + s64(0x9E3779B97F4A7C15)
+    x = (x ^ _lsr(x, 30)) * s64(0xBF58476D1CE4E5B9)
+    x = (x ^ _lsr(x, 27)) * s64(0x94D049BB133111EB)
+    x = x ^ _lsr(x, 31)
+    return units * 65536 + (x & 0xFFFF)
 
 
 def _arc_cost_int_vec(cost, kind, a, b):

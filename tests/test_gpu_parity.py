@@ -345,3 +345,45 @@ def test_inference_hungarian_mode_end_to_end(weights):
     for f, rows in enumerate(ref['tables']):
         assert [int(n[-3:]) for n in tabs[f].index] == [r[0] for r in rows]
         assert list(tabs[f].anchor_x) == [r[2] for r in rows]
+
+
+# ----------------------------------------------------------------------------------------- a-9 on a real mask
+def test_path_cost_masked_grid_matches_oracle():
+    """Corridor mask (BASELINE config 5 style), sources/targets on and off the mask, one outside the grid."""
+    H, W = 300, 420
+    mask = synth.corridor_mask(H, W, width=24, pitch=80)
+    mask[100:140, :] = False                                    # a gap the paths must cross or walk around
+    rng = np.random.default_rng(5)
+    na, nb = 14, 17
+    xa, ya = rng.integers(0, W, na), rng.integers(0, H, na)
+    xb, yb = rng.integers(0, W, nb), rng.integers(0, H, nb)
+    xa[0], ya[0] = -2, 10                                        # outside the grid
+    xb[1], yb[1] = xa[2], ya[2]                                  # identical points: one cell
+    for conn8 in (False, True):
+        D = hp.path_cost(dev(xa, torch.int32), dev(ya, torch.int32), dev(xb, torch.int32), dev(yb, torch.int32),
+                         H, W, dev(mask.astype(np.uint8)), 500, conn8).cpu().numpy()
+        ref = orc.path_matrix((None, xa, ya), (None, xb, yb), H, W, mask, 500, conn8)
+        assert np.array_equal(D, ref), (D != ref).sum()
+    assert (D[0] == 500).all() and D[2, 1] == 1
+    # an all-ones mask through the masked kernel equals the closed form
+    ones = np.ones((H, W), np.uint8)
+    D1 = hp.path_cost(dev(xa, torch.int32), dev(ya, torch.int32), dev(xb, torch.int32), dev(yb, torch.int32),
+                      H, W, dev(ones), 500, False).cpu().numpy()
+    D0 = hp.path_cost(dev(xa, torch.int32), dev(ya, torch.int32), dev(xb, torch.int32), dev(yb, torch.int32),
+                      H, W, None, 500, False).cpu().numpy()
+    assert np.array_equal(D1, D0)
+
+
+def test_inference_with_mask_end_to_end(weights):
+    """512x512x7 with a corridor mask: the masked arc builder + flow solve equal the oracle's."""
+    import axtrack_amd
+    frames = synth.synth_frames(7, 512, 512, seed=31)
+    mask = synth.corridor_mask(512, 512, width=40, pitch=128)
+    P = params.load_parameters()
+    model = axtrack_amd.Detector(weights, max_batch=8)
+    tl = axtrack_amd.Timelapse(frames, name='synth', mask=mask)
+    ad = axtrack_amd.inference(tl, model, None, P, None, None, None)
+    yolo = ad._yolo.cpu().numpy()
+    ref = orc.inference(frames, weights, mask=mask, P=orc.DEFAULTS, yolo=list(yolo))
+    got = tracks_from_next(np.zeros(len(ad._track_flat)), ad._track_flat, ad._offs)
+    assert got == ref['trajs'] and ad.mcf_total_cost == ref['total_cost']

@@ -1,0 +1,76 @@
+"""The multi-GPU exchange step on CPU: two processes (gloo) each hold the detections of their
+frame block, one all-gather gives both the whole timelapse, and the replicated integer-cost solve
+returns identical trajectories on both ranks (and the same as a single process)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from axtrack_amd import sharded, hotpath as hp
+    from oracle import oracle as orc
+    from helpers import golden_dets, csr_arcs_from_oracle, node_costs_from_oracle
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'detect_ragged.npz'))
+    dets = golden_dets(g)                                   # 2 frames -> one per rank
+    start, per = sharded.frame_block(len(dets), rank, world)
+    cap = 640
+    mine = dets[start:start + per]
+    conf = torch.zeros((per, cap)); x = torch.zeros((per, cap), dtype=torch.int32); y = torch.zeros((per, cap), dtype=torch.int32)
+    cnt = torch.zeros((per,), dtype=torch.int32)
+    for f, (c, xx, yy) in enumerate(mine):
+        n = len(c)
+        conf[f, :n] = torch.from_numpy(c.copy()); x[f, :n] = torch.from_numpy(xx.astype(np.int32))
+        y[f, :n] = torch.from_numpy(yy.astype(np.int32)); cnt[f] = n
+    gc, gx, gy, gn = sharded.all_gather_detections(conf, x, y, cnt)
+    all_dets = [(gc[f, :gn[f]].numpy(), gx[f, :gn[f]].numpy().astype(np.int64), gy[f, :gn[f]].numpy().astype(np.int64))
+                for f in range(world * per)]
+    ok_gather = all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+                    for a, b in zip(all_dets, dets))
+    P = dict(orc.DEFAULTS, MCF_MIN_FLOW=1)
+    row_ptr, col, length, gap, cost, offs = csr_arcs_from_oracle(all_dets, int(g['H']), int(g['W']), P)
+    obs_i, en_i, ex_i, _ = node_costs_from_oracle(all_dets, P)
+    nxt, track, n_tracks, total = hp.mcf_solve(obs_i, en_i, ex_i, row_ptr, col, cost, 1, 450)
+    q.put((rank, ok_gather, n_tracks, total, track.tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_and_replicated_solve():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] and res[1][1], 'gathered detections differ from the global list'
+    assert res[0][2:] == res[1][2:], 'ranks disagree on the replicated solve'
+    assert res[0][2] >= 1
+
+
+def test_frame_block_partition():
+    from axtrack_amd import sharded
+    assert [sharded.frame_block(1008, r, 8) for r in (0, 7)] == [(0, 126), (882, 126)]
+    import pytest
+    with pytest.raises(ValueError):
+        sharded.frame_block(10, 0, 4)
