@@ -35,183 +35,35 @@ constexpr int kOut = AXT_YOLO_FLOATS;  // 432
 constexpr int kOutPad = 448;           // 7 x 64
 
 // ------------------------------------------------------------------------------------------------
-// conv kernel geometry (compile time)
+// conv kernels: shared pieces
 // ------------------------------------------------------------------------------------------------
-template <int STRIDE, int MT>
-struct Geo {
-    static constexpr int TW = 16, TH = 4 * MT;
-    static constexpr int PH = (TH - 1) * STRIDE + 3, PW = (TW - 1) * STRIDE + 3;
-    // plane stride: stride-1 reads want lanes 16..31 (next channel) 16 banks away; stride-2 reads
-    // touch every other bank, the next channel must land on the odd ones
-    static constexpr int RAW = PH * PW;
-    static constexpr int PLANE = (STRIDE == 1) ? (RAW + ((16 - RAW % 32) + 32) % 32) : (RAW | 1);
-};
 constexpr int npadw(int nt) { return (nt % 2) ? nt * 16 : nt * 16 + 16; }   // row stride == 16 (mod 32)
 
 struct TileList { int n; short yx[2 * 256]; };
 
-// first layer: K index k -> offset of (c, ky, kx) inside the LDS patch, k = c*9 + ky*3 + kx (k < 45)
-template <int PLANE, int PW>
-__device__ __forceinline__ int first_koff(int k)
+// Persistent workgroups: the grid is a multiple of 8 and every workgroup walks a strided list of work items
+// (batch item, channel group, 16x16 output tile). Workgroups are dealt round-robin over the 8 XCDs
+// (block b -> XCD b % 8), so the list is cut into 8 contiguous ranges, one per XCD: neighbouring tiles -- which
+// share halos -- and neighbouring batch items -- which share 4 of their 5 input frames -- meet in one L2.
+struct WorkRange { int begin, end, step; };
+__device__ __forceinline__ WorkRange my_work(int nwork)
 {
-    if (k >= 45) return 0;   // zero weights there
-    const int c = k / 9, r = k % 9;
-    return c * PLANE + (r / 3) * PW + (r % 3);
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd_wg = gridDim.x >> 3;
+    const int per_xcd = (nwork + 7) >> 3;
+    WorkRange r;
+    r.begin = xcd * per_xcd + slot;
+    r.end = min(nwork, (xcd + 1) * per_xcd);
+    r.step = per_xcd_wg;
+    return r;
 }
 
-// ------------------------------------------------------------------------------------------------
-// conv3x3 + folded BN + LeakyReLU (+ maxpool 2x2)
-//   grid: x = spatial tiles (tiles_x * tiles_y), y = output-channel group, z = batch item
-//   block: 256 threads = 4 waves; wave w owns rows [w*MT, (w+1)*MT) of the TH x 16 output tile and all
-//   NT*16 channels of the group: MT x NT accumulator tiles of 16 px x 16 ch.
-// ------------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int STRIDE, bool POOL, int CCH, int MT, int NT, bool FIRST>
-__global__ __launch_bounds__(256) void conv3x3_mfma(
-    const float *__restrict__ in,       // FIRST: frames [T_all,Hf,Wf]; else activations [B,CIN,Hin,Win]
-    const float *__restrict__ wpk,      // packed weights [ngroup][nchunk][KROWS][NPADW]
-    const float *__restrict__ bias,     // folded bias [COUT]
-    float *__restrict__ out,            // [B,COUT,Hout,Wout]
-    int Hin, int Win, int tiles_x,
-    int Hf, int Wf, int t0, int tstep, int item0, int n_tiles, TileList tl)
+// epilogue shared by the conv kernels: + folded bias, LeakyReLU(0.1), optional 2x2 max, store NCHW.
+// acc[m][n][j]: pixel (row y0 + wave*MT + m, x0 + q*4 + j), channel grp*NT*16 + n*16 + p.
+template <int COUT, bool POOL, int MT, int NT>
+__device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[MT][NT], const float *__restrict__ bias,
+                                              float *__restrict__ out, int b, int grp, int y0, int x0, int wave, int p,
+                                              int q, int Hout, int Wout)
 {
-    using G = Geo<STRIDE, MT>;
-    constexpr int PH = G::PH, PW = G::PW, PLANE = G::PLANE, TH = G::TH;
-    constexpr int NPADW = npadw(NT);
-    constexpr int NCHUNK = FIRST ? 1 : CIN / CCH;
-    constexpr int KSTEPS = FIRST ? 12 : 9 * CCH / 4;       // k-steps of 4 per chunk
-    constexpr int KROWS = KSTEPS * 4;
-    static_assert(FIRST || CIN % CCH == 0, "CIN must be a multiple of CCH");
-    static_assert(CCH % 4 == 0, "CCH must be a multiple of 4");
-    static_assert(!POOL || MT % 2 == 0, "pooling pairs rows inside a wave");
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *patch = smem;                          // [CCH][PLANE]
-    float *wl = smem + ((CCH * PLANE + 3) & ~3);   // [KROWS][NPADW]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int p = lane & 15, q = lane >> 4;
-    const int b = blockIdx.z, grp = blockIdx.y;
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
-    const int y0 = ty * TH, x0 = tx * 16;                 // output tile origin (before pooling)
-    const int iy0 = y0 * STRIDE - 1, ix0 = x0 * STRIDE - 1;
-
-    // where this item's input lives
-    const float *src;
-    int lim_y, lim_x;        // valid input rows/cols are [0, lim)
-    long cstride;            // channel stride in elements
-    int rstride;
-    if constexpr (FIRST) {
-        const int item = item0 + b;
-        const int t = t0 + (item / n_tiles) * tstep, k = item % n_tiles;
-        const int oy = tl.yx[2 * k] * AXT_TILE, ox = tl.yx[2 * k + 1] * AXT_TILE;
-        src = in + ((long)t * Hf + oy) * Wf + ox;
-        cstride = (long)Hf * Wf;
-        rstride = Wf;
-        lim_y = min(AXT_TILE, Hf - oy);
-        lim_x = min(AXT_TILE, Wf - ox);
-    } else {
-        src = in + (long)b * CIN * Hin * Win;
-        cstride = (long)Hin * Win;
-        rstride = Win;
-        lim_y = Hin;
-        lim_x = Win;
-    }
-
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    int koff[FIRST ? KSTEPS : 1];
-    if constexpr (FIRST) {
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) koff[s] = first_koff<PLANE, PW>(s * 4 + q);
-    }
-
-    const int a_base = (FIRST ? 0 : q * PLANE) + (wave * MT * STRIDE) * PW + p * STRIDE;
-    const int b_base = q * NPADW + p;
-    const float *wsrc = wpk + (long)grp * NCHUNK * KROWS * NPADW;
-
-    // ---- staging plan: every thread moves NPE patch elements and NWE float4 of weights per chunk.
-    // Their positions do not depend on the chunk, so the index arithmetic is done once; per chunk all
-    // loads are issued back to back into registers (no wait in between) and written to LDS after the
-    // barrier, while the next chunk's loads are already in flight behind the MFMAs.
-    constexpr int NPC = FIRST ? CIN : CCH;
-    constexpr int NPE = (NPC * PH * PW + 255) / 256;
-    constexpr int NW4 = KROWS * NPADW / 4;
-    constexpr int NWE = (NW4 + 255) / 256;
-    int goff[NPE], loff[NPE];            // global offset inside the chunk (-1: zero padding), LDS offset (-1: none)
-#pragma unroll
-    for (int k = 0; k < NPE; ++k) {
-        const int e = tid + k * 256;
-        const int c = e / (PH * PW), rem = e - c * (PH * PW);
-        const int r = rem / PW, col = rem - r * PW;
-        const int gy = iy0 + r, gx = ix0 + col;
-        const bool in_patch = e < NPC * PH * PW;
-        const bool in_img = in_patch && gy >= 0 && gy < lim_y && gx >= 0 && gx < lim_x;
-        loff[k] = in_patch ? c * PLANE + r * PW + col : -1;
-        goff[k] = in_img ? (int)(c * cstride + (long)gy * rstride + gx) : -1;
-    }
-    float pv[NPE];
-    f32x4 wv[NWE];
-    auto load_chunk = [&](int chunk) {
-        const float *csrc = src + (long)chunk * CCH * cstride;
-#pragma unroll
-        for (int k = 0; k < NPE; ++k) pv[k] = goff[k] >= 0 ? csrc[goff[k]] : 0.f;
-        const f32x4 *w4 = reinterpret_cast<const f32x4 *>(wsrc + (long)chunk * KROWS * NPADW);
-#pragma unroll
-        for (int k = 0; k < NWE; ++k) {
-            const int e = tid + k * 256;
-            wv[k] = (NW4 % 256 == 0 || e < NW4) ? w4[e] : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    auto store_chunk = [&]() {
-#pragma unroll
-        for (int k = 0; k < NPE; ++k)
-            if (loff[k] >= 0) patch[loff[k]] = pv[k];
-        f32x4 *l4 = reinterpret_cast<f32x4 *>(wl);
-#pragma unroll
-        for (int k = 0; k < NWE; ++k) {
-            const int e = tid + k * 256;
-            if (NW4 % 256 == 0 || e < NW4) l4[e] = wv[k];
-        }
-    };
-
-    load_chunk(0);
-    for (int chunk = 0; chunk < NCHUNK; ++chunk) {
-        if (chunk) __syncthreads();          // every wave is done reading the previous chunk
-        store_chunk();
-        __syncthreads();
-        if (chunk + 1 < NCHUNK) load_chunk(chunk + 1);
-
-        // ---- MFMA over the chunk
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            float a[MT], bw[NT];
-            if constexpr (FIRST) {
-#pragma unroll
-                for (int m = 0; m < MT; ++m) a[m] = patch[a_base + koff[s] + m * STRIDE * PW];
-            } else {
-                constexpr int CG = CCH / 4;
-                const int kk = s / CG, cg = s % CG;      // (ky,kx) major, channel group minor
-                const int ky = kk / 3, kx = kk % 3;
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    a[m] = patch[a_base + cg * 4 * PLANE + (m * STRIDE + ky) * PW + kx];
-            }
-#pragma unroll
-            for (int n = 0; n < NT; ++n) bw[n] = wl[b_base + s * 4 * NPADW + n * 16];
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bw[n], acc[m][n], 0, 0, 0);
-        }
-    }
-
-    // ---- epilogue: + folded bias, LeakyReLU(0.1), optional 2x2 max, store NCHW
-    const int Hout = (Hin / STRIDE) / (POOL ? 2 : 1), Wout = (Win / STRIDE) / (POOL ? 2 : 1);
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int ch = grp * NT * 16 + n * 16 + p;
@@ -251,12 +103,335 @@ __global__ __launch_bounds__(256) void conv3x3_mfma(
     }
 }
 
-template <int CIN, int COUT, int STRIDE, bool POOL, int CCH, int MT, int NT, bool FIRST>
-constexpr size_t conv_lds_bytes()
+// ------------------------------------------------------------------------------------------------
+// stride-1 conv3x3 + folded BN + LeakyReLU (+ maxpool 2x2): conv blocks 2,4,5,7,8,10
+//   work item = (batch item, channel group of NT*16, 16x16 output tile); block: 256 threads = 4 waves, wave w owns
+//   rows [4w, 4w+4) of the tile and all NT*16 channels of the group: 4 x NT accumulator tiles of 16 px x 16 ch.
+//   K = 9*CIN runs in chunks of CCH channels: the (18 x 18 x CCH) input patch and the chunk's weights are staged in
+//   LDS. The chunks are software-pipelined: the global loads of chunk k+1 are issued into registers before the
+//   MFMAs of chunk k and written to LDS after them (async-STAGE split).
+//   LDS patch layout: channel-planar, plane stride == 16 (mod 32) dwords: the four k of an MFMA step are four
+//   channels, lanes 16..31 then read 16 banks away from lanes 0..15 (conflict-free ds_read_b32).
+// ------------------------------------------------------------------------------------------------
+template <int CCH>
+struct GeoS1 {
+    static constexpr int MT = 4, TH = 16, PH = 18, PW = 18, RAW = PH * PW;
+    static constexpr int PLANE = RAW + ((16 - RAW % 32) + 32) % 32;        // 336
+    static constexpr int KSTEPS = 9 * CCH / 4, KROWS = KSTEPS * 4;
+};
+
+template <int CIN, int COUT, bool POOL, int CCH, int NT>
+__global__ __launch_bounds__(256, 2) void conv3x3_mfma(
+    const float *__restrict__ in,       // activations [B,CIN,Hin,Hin]
+    const float *__restrict__ wpk,      // packed weights [ngroup][nchunk][KROWS][NPADW]
+    const float *__restrict__ bias,     // folded bias [COUT]
+    float *__restrict__ out,            // [B,COUT,Hout,Hout]
+    int Hin, int ngroups, int B)
 {
-    using G = Geo<STRIDE, MT>;
-    constexpr int KROWS = FIRST ? 48 : 9 * CCH;
-    return (size_t)(((CCH * G::PLANE + 3) & ~3) + KROWS * npadw(NT)) * sizeof(float);
+    using G = GeoS1<CCH>;
+    constexpr int MT = G::MT, PH = G::PH, PW = G::PW, PLANE = G::PLANE, KSTEPS = G::KSTEPS, KROWS = G::KROWS;
+    constexpr int NPADW = npadw(NT);
+    constexpr int NCHUNK = CIN / CCH;
+    static_assert(CIN % CCH == 0 && CCH % 4 == 0, "CIN must be a multiple of CCH, CCH of 4");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *patch = smem;                            // [CCH][PLANE]
+    float *wl = smem + ((CCH * PLANE + 3) & ~3);     // [KROWS][NPADW]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 15, q = lane >> 4;
+    const int tiles_x = Hin / 16, ntile = tiles_x * tiles_x;
+    // one work item per workgroup; blocks are dealt round-robin over the 8 XCDs, so give each XCD a contiguous
+    // range of items (bijective remap): neighbouring tiles, which share halos and weights, meet in one L2
+    int w;
+    {
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int qq = nwg >> 3, rr = nwg & 7;
+        w = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + slot;
+    }
+    const int tile = w % ntile, rest = w / ntile;
+    const int grp = rest % ngroups, b = rest / ngroups;
+    const int y0 = (tile / tiles_x) * 16, x0 = (tile % tiles_x) * 16;
+    const long cstride = (long)Hin * Hin;
+    const int Hout = POOL ? Hin / 2 : Hin;
+
+    // staging plan: element e = tid + k*256 of the patch is (channel c, row r, col). Branch-free: elements past
+    // the patch go to a dummy LDS word, elements outside the image load from a clamped (valid) address and are
+    // zeroed by a select. Per chunk all loads are issued back to back into registers and written to LDS after the
+    // barrier, while the next chunk's loads are already in flight behind the MFMAs (async-STAGE split).
+    constexpr int NPE = (CCH * PH * PW + 255) / 256;
+    constexpr int NW4 = KROWS * NPADW / 4;
+    constexpr int NWE = (NW4 + 255) / 256;
+    constexpr int DUMMY = CCH * PLANE - 1;       // last (padding) word of the last plane, never read by the MFMAs
+    static_assert(PLANE > PH * PW, "the plane padding provides the dummy word");
+    int loff[NPE], goff[NPE];
+#pragma unroll
+    for (int k = 0; k < NPE; ++k) {
+        const int e = tid + k * 256;
+        const int c = e / (PH * PW), rem = e - c * (PH * PW);
+        const int r = rem / PW, col = rem - r * PW;
+        const int gy = y0 - 1 + r, gx = x0 - 1 + col;
+        const bool in_patch = e < CCH * PH * PW;
+        const bool ok = in_patch && gy >= 0 && gy < Hin && gx >= 0 && gx < Hin;
+        loff[k] = in_patch ? c * PLANE + r * PW + col : DUMMY;
+        const int g = c * (int)cstride + gy * Hin + gx;
+        goff[k] = ok ? g : -1;
+    }
+    float pv[NPE];
+    f32x4 wv[NWE];
+    const float *isrc = in + (long)b * CIN * cstride;
+    const float *wsrc = wpk + (long)grp * NCHUNK * KROWS * NPADW;
+    auto load_chunk = [&](int chunk) {
+        const float *csrc = isrc + (long)chunk * CCH * cstride;
+#pragma unroll
+        for (int k = 0; k < NPE; ++k) {
+            const float v = csrc[goff[k] < 0 ? 0 : goff[k]];
+            pv[k] = goff[k] < 0 ? 0.f : v;
+        }
+        const f32x4 *w4 = reinterpret_cast<const f32x4 *>(wsrc + (long)chunk * KROWS * NPADW);
+#pragma unroll
+        for (int k = 0; k < NWE; ++k) {
+            const int e = tid + k * 256;
+            wv[k] = w4[(NW4 % 256 == 0 || e < NW4) ? e : 0];
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int k = 0; k < NPE; ++k) patch[loff[k]] = pv[k];
+        f32x4 *l4 = reinterpret_cast<f32x4 *>(wl);
+#pragma unroll
+        for (int k = 0; k < NWE; ++k) {
+            const int e = tid + k * 256;
+            if (NW4 % 256 == 0 || k + 1 < NWE || e < NW4) l4[e] = wv[k];
+        }
+    };
+
+    const int a_base = q * PLANE + (wave * MT) * PW + p;
+    const int b_base = q * NPADW + p;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    load_chunk(0);
+    for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+        if (chunk) __syncthreads();          // every wave is done reading the previous chunk
+        store_chunk();
+        __syncthreads();
+        if (chunk + 1 < NCHUNK) load_chunk(chunk + 1);
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            float a[MT], bw[NT];
+            constexpr int CG = CCH / 4;
+            const int kk = s / CG, cg = s % CG;      // (ky,kx) major, channel group minor
+            const int ky = kk / 3, kx = kk % 3;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) a[m] = patch[a_base + cg * 4 * PLANE + (m + ky) * PW + kx];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bw[n] = wl[b_base + s * 4 * NPADW + n * 16];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bw[n], acc[m][n], 0, 0, 0);
+        }
+    }
+    conv_epilogue<COUT, POOL, MT, NT>(acc, bias, out, b, grp, y0, x0, wave, p, q, Hout, Hout);
+}
+
+// ------------------------------------------------------------------------------------------------
+// stride-2 conv3x3 (conv blocks 0 and 1): low arithmetic intensity, so data movement decides the speed.
+//   * the 33-row input patch is staged as rows of 40 floats starting 3 columns left of the patch
+//     (2*x0 - 4, a multiple of 4): aligned 16-byte global loads and ds_write_b128 instead of scalars;
+//   * K is ordered k = c*9 + ky*3 + kx per chunk and addressed through a per-lane offset table, so the four
+//     k of one MFMA step mostly differ in kx: with stride-2 pixel addresses (even banks) the next k lands on
+//     the odd banks -- conflict-free without padding the planes;
+//   * ALL the layer's weights stay in LDS for the life of the (persistent) workgroup; only patches stream,
+//     software-pipelined across chunks and tiles as in conv3x3_mfma.
+//   conv block 0 (FIRST) gathers its 5 channels straight from frames t..t+4 of the timelapse at the tile origin
+//   (fuses Timelapse.get_frametiles_stack, Timelapse.py:111-125,150-157), zero beyond the tile and the frame.
+// ------------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int NPC, int NT, bool FIRST, int WPS>
+__global__ __launch_bounds__(256) void conv3x3_s2_mfma(
+    const float *__restrict__ in, const float *__restrict__ wpk, const float *__restrict__ bias,
+    float *__restrict__ out, int Hin, int B,
+    int Hf, int Wf, int t0, int tstep, int item0, int n_tiles, TileList tl)
+{
+    constexpr int MT = 4, PH = 33, RW = 40, PLANE = PH * RW;
+    constexpr int NCHUNK = CIN / NPC;
+    constexpr int KREAL = 9 * NPC, KSTEPS = (KREAL + 3) / 4, KROWS = KSTEPS * 4;
+    constexpr int NPADW = npadw(NT);
+    static_assert(CIN % NPC == 0, "CIN must be a multiple of the chunk");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *patch = smem;                      // [NPC][33][40]
+    float *wl = smem + NPC * PLANE;           // [NCHUNK][KROWS][NPADW]  (whole layer)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 15, q = lane >> 4;
+    const int tiles_x = Hin / 32, ntile = tiles_x * tiles_x;     // output is Hin/2, tiles of 16
+    const WorkRange wr = my_work(ntile * B);
+    if (wr.begin >= wr.end) return;
+
+    // the layer's weights: once per workgroup
+    {
+        constexpr int NW4 = NCHUNK * KROWS * NPADW / 4;
+        const f32x4 *w4 = reinterpret_cast<const f32x4 *>(wpk);
+        f32x4 *l4 = reinterpret_cast<f32x4 *>(wl);
+        for (int e = tid; e < NW4; e += 256) l4[e] = w4[e];
+    }
+
+    int koff[KSTEPS];
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+        const int k = s * 4 + q;
+        const int kk = k < KREAL ? k : 0;                  // padded k rows carry zero weights
+        koff[s] = (kk / 9) * PLANE + ((kk % 9) / 3) * RW + (kk % 3) + 3;
+    }
+    const int a_base = (wave * MT * 2) * RW + 2 * p;
+    const int b_base = q * NPADW + p;
+
+    // staging plan (float4 granularity): element e = tid + k*256 is (channel c, row r, 4-column segment).
+    // Branch-free: segments past the patch go to a dummy LDS slot (an extra 16 bytes behind the weights), rows or
+    // segments outside the image load from a clamped address and are zeroed by selects.
+    constexpr int NP4 = NPC * PH * (RW / 4);
+    constexpr int NPE = (NP4 + 255) / 256;
+    constexpr int DUMMY = NPC * PLANE + NCHUNK * KROWS * NPADW;     // float offset of the spare float4
+    int loff[NPE];
+#pragma unroll
+    for (int k = 0; k < NPE; ++k) {
+        const int e = tid + k * 256;
+        const int c = e / (PH * (RW / 4)), rem = e - c * (PH * (RW / 4));
+        const int r = rem / (RW / 4), seg = rem - r * (RW / 4);
+        loff[k] = e < NP4 ? (c * PLANE + r * RW + 4 * seg) : DUMMY;
+    }
+    int goff[NPE];                           // global offset inside (item, chunk 0) of the segment's first float
+    int gx0[NPE];                            // its column, or a large negative number when the row is invalid
+    f32x4 pv[NPE];
+
+    int cur_b = 0, cur_y0 = 0, cur_x0 = 0;
+    int nxt_b = 0, nxt_y0 = 0, nxt_x0 = 0, nxt_limx = 0, nxt_cstride = 0, nxt_aligned = 0;
+    long nxt_src = 0;
+    auto decode_plan = [&](int w) {
+        const int tile = w % ntile;
+        nxt_b = w / ntile;
+        nxt_y0 = (tile / tiles_x) * 16;
+        nxt_x0 = (tile % tiles_x) * 16;
+        int lim_y, rstride;
+        if constexpr (FIRST) {
+            const int item = item0 + nxt_b;
+            const int t = t0 + (item / n_tiles) * tstep, k = item % n_tiles;
+            const int oy = tl.yx[2 * k] * AXT_TILE, ox = tl.yx[2 * k + 1] * AXT_TILE;
+            nxt_src = ((long)t * Hf + oy) * Wf + ox;
+            nxt_cstride = Hf * Wf;
+            rstride = Wf;
+            lim_y = min(AXT_TILE, Hf - oy);
+            nxt_limx = min(AXT_TILE, Wf - ox);
+            nxt_aligned = (Wf % 4 == 0) && (nxt_limx % 4 == 0);
+        } else {
+            nxt_src = (long)nxt_b * CIN * Hin * Hin;
+            nxt_cstride = Hin * Hin;
+            rstride = Hin;
+            lim_y = Hin;
+            nxt_limx = Hin;
+            nxt_aligned = 1;
+        }
+        const int iy0 = nxt_y0 * 2 - 1, jx0 = nxt_x0 * 2 - 4;     // first staged row / column (a multiple of 4)
+#pragma unroll
+        for (int k = 0; k < NPE; ++k) {
+            const int e = tid + k * 256;
+            const int c = e / (PH * (RW / 4)), rem = e - c * (PH * (RW / 4));
+            const int r = rem / (RW / 4), seg = rem - r * (RW / 4);
+            const int gy = iy0 + r, gx = jx0 + 4 * seg;
+            const bool rowok = e < NP4 && gy >= 0 && gy < lim_y;
+            goff[k] = c * nxt_cstride + gy * rstride + gx;
+            gx0[k] = rowok ? gx : -(1 << 20);
+        }
+    };
+    auto load_chunk = [&](int chunk) {       // loads (nxt item or current item: the plan in goff/gx0), chunk
+        const float *csrc = in + nxt_src + (long)chunk * NPC * nxt_cstride;
+        if (nxt_aligned) {
+#pragma unroll
+            for (int k = 0; k < NPE; ++k) {
+                const bool ok = gx0[k] >= 0 && gx0[k] + 3 < nxt_limx;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(csrc + (ok ? goff[k] : 0));
+                pv[k] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NPE; ++k) {
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = gx0[k] + j >= 0 && gx0[k] + j < nxt_limx;
+                    const float t = csrc[ok ? goff[k] + j : 0];
+                    v[j] = ok ? t : 0.f;
+                }
+                pv[k] = v;
+            }
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int k = 0; k < NPE; ++k) *reinterpret_cast<f32x4 *>(patch + loff[k]) = pv[k];
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int w = wr.begin, chunk = 0;
+    decode_plan(w);
+    cur_b = nxt_b; cur_y0 = nxt_y0; cur_x0 = nxt_x0;
+    load_chunk(0);
+    bool first = true;
+    const int Hout = Hin / 2;
+#pragma unroll 1
+    for (;;) {
+        if (!first) __syncthreads();
+        first = false;
+        store_chunk();
+        __syncthreads();                      // also covers the one-time weight staging
+        const bool last_chunk = (chunk == NCHUNK - 1);
+        const bool has_next = w + wr.step < wr.end;
+        if (!last_chunk) {
+            load_chunk(chunk + 1);
+        } else if (has_next) {
+            decode_plan(w + wr.step);
+            load_chunk(0);
+        }
+        const float *wc = wl + chunk * KROWS * NPADW;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            float a[MT], bw[NT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) a[m] = patch[a_base + koff[s] + m * 2 * RW];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bw[n] = wc[b_base + s * 4 * NPADW + n * 16];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bw[n], acc[m][n], 0, 0, 0);
+        }
+        if (last_chunk) {
+            conv_epilogue<COUT, false, MT, NT>(acc, bias, out, cur_b, 0, cur_y0, cur_x0, wave, p, q, Hout, Hout);
+            if (!has_next) break;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            w += wr.step;
+            cur_b = nxt_b; cur_y0 = nxt_y0; cur_x0 = nxt_x0;
+            chunk = 0;
+        } else {
+            ++chunk;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -348,9 +523,10 @@ __global__ void reduce_bias_act(const float *__restrict__ slab, int S, int M, in
 // host side
 // ------------------------------------------------------------------------------------------------
 struct ConvPlan { int cch, nt, ngroups; };
-static const ConvPlan kPlan[8] = {{8, 2, 1}, {4, 3, 1}, {8, 5, 1}, {8, 5, 1}, {8, 5, 1}, {8, 5, 1}, {8, 5, 1}, {8, 5, 2}};
+static const ConvPlan kPlan[8] = {{5, 2, 1}, {5, 3, 1}, {8, 5, 1}, {8, 5, 1}, {8, 5, 1}, {8, 5, 1}, {8, 5, 1}, {8, 5, 2}};
 
-constexpr int kChunkA = 16;       // tile-forwards per launch for the large-activation layers (fits the Infinity Cache)
+constexpr int kChunkA = 16;       // tile-forwards per launch for conv blocks 0-2 (activations fit the Infinity Cache)
+constexpr int kChunkB = 32;       // tile-forwards per launch for conv blocks 3-4 (64x64 maps: 1024 workgroups per launch)
 constexpr int kFc1Split = 8, kFc2Split = 4, kFc3Split = 4;
 
 }  // namespace
@@ -418,17 +594,17 @@ int dev_alloc(axt_detector *d, T **p, size_t n)
 }
 
 // Packs one conv block: folds BN (f64), lays weights out as [group][chunk][krow][NPADW].
-// krow order inside a chunk: ((ky*3+kx) * CCH/4 + cg) * 4 + kk  <->  channel chunk*CCH + cg*4 + kk
-// first layer: krow = c*9 + ky*3 + kx (45 rows, padded to 48).
+// krow order inside a chunk, stride-1 layers: ((ky*3+kx) * CCH/4 + cg) * 4 + kk  <->  channel chunk*CCH + cg*4 + kk
+// stride-2 layers (conv3x3_s2_mfma): krow = c*9 + ky*3 + kx with c the channel inside the chunk (45 rows, padded to 48).
 void pack_conv(int li, const float *w, const float *b, const float *gamma, const float *beta,
                const float *mean, const float *var, std::vector<float> &wp, std::vector<float> &bp)
 {
     const ConvSpec &cs = kConv[li];
     const ConvPlan &pl = kPlan[li];
     const int NPADW = npadw(pl.nt);
-    const bool first = li == 0;
-    const int nchunk = first ? 1 : cs.cin / pl.cch;
-    const int krows = first ? 48 : 9 * pl.cch;
+    const bool first = cs.stride == 2;          // table-ordered K
+    const int nchunk = cs.cin / pl.cch;
+    const int krows = first ? ((9 * pl.cch + 3) / 4) * 4 : 9 * pl.cch;
     wp.assign((size_t)pl.ngroups * nchunk * krows * NPADW, 0.f);
     bp.assign(cs.cout, 0.f);
     for (int co = 0; co < cs.cout; ++co) {
@@ -441,8 +617,8 @@ void pack_conv(int li, const float *w, const float *b, const float *gamma, const
                     const float v = (float)((double)w[(((size_t)co * cs.cin + ci) * 3 + ky) * 3 + kx] * sc);
                     int chunk, krow;
                     if (first) {
-                        chunk = 0;
-                        krow = ci * 9 + ky * 3 + kx;
+                        chunk = ci / pl.cch;
+                        krow = (ci % pl.cch) * 9 + ky * 3 + kx;
                     } else {
                         chunk = ci / pl.cch;
                         const int c = ci % pl.cch;
@@ -453,27 +629,59 @@ void pack_conv(int li, const float *w, const float *b, const float *gamma, const
     }
 }
 
-template <int CIN, int COUT, int STRIDE, bool POOL, int CCH, int MT, int NT, bool FIRST>
-int launch_conv(const float *in, const float *w, const float *bias, float *out, int Hin, int ngroups, int B,
-                hipStream_t st, int Hf = 0, int Wf = 0, int t0 = 0, int tstep = 1, int item0 = 0, int n_tiles = 1,
-                const TileList *tl = nullptr)
+// persistent grids: a multiple of 8 (one slice per XCD), at most `per_cu` workgroups per CU
+int persistent_grid(int nwork, int per_cu)
 {
-    auto kern = conv3x3_mfma<CIN, COUT, STRIDE, POOL, CCH, MT, NT, FIRST>;
-    constexpr size_t lds = conv_lds_bytes<CIN, COUT, STRIDE, POOL, CCH, MT, NT, FIRST>();
+    int g = 256 * per_cu;
+    if (g > nwork) g = nwork;
+    g = ((g + 7) / 8) * 8;
+    return g;
+}
+
+template <int CIN, int COUT, bool POOL, int CCH, int NT>
+int launch_conv(const float *in, const float *w, const float *bias, float *out, int Hin, int ngroups, int B,
+                hipStream_t st)
+{
+    auto kern = conv3x3_mfma<CIN, COUT, POOL, CCH, NT>;
+    using G = GeoS1<CCH>;
+    constexpr size_t lds = (size_t)(((CCH * G::PLANE + 3) & ~3) + G::KROWS * npadw(NT)) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         AXT_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    const int Hpre = Hin / STRIDE;                 // output size before pooling
-    const int TH = 4 * MT;
-    AXT_REQUIRE(Hpre % TH == 0 && Hpre % 16 == 0, "conv: output %d not a multiple of the tile", Hpre);
-    const int tiles_x = Hpre / 16, tiles_y = Hpre / TH;
+    AXT_REQUIRE(Hin % 16 == 0, "conv: map size %d not a multiple of the 16x16 tile", Hin);
+    const int nwork = (Hin / 16) * (Hin / 16) * ngroups * B;
+    hipLaunchKernelGGL(kern, dim3(nwork), dim3(256), lds, st, in, w, bias, out, Hin, ngroups, B);
+    AXT_LAUNCH_CHECK();
+    return AXT_OK;
+}
+
+template <int CIN, int COUT, int NPC, int NT, bool FIRST, int WPS>
+int launch_conv_s2(const float *in, const float *w, const float *bias, float *out, int Hin, int B, hipStream_t st,
+                   int Hf = 0, int Wf = 0, int t0 = 0, int tstep = 1, int item0 = 0, int n_tiles = 1,
+                   const TileList *tl = nullptr)
+{
+    auto kern = conv3x3_s2_mfma<CIN, COUT, NPC, NT, FIRST, WPS>;
+    constexpr int KROWS = ((9 * NPC + 3) / 4) * 4;
+    constexpr size_t lds = (size_t)(NPC * 33 * 40 + (CIN / NPC) * KROWS * npadw(NT) + 4) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        AXT_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    AXT_REQUIRE(Hin % 32 == 0, "conv: map size %d not a multiple of the tile", Hin);
     TileList dummy;
     dummy.n = 0;
-    dim3 grid(tiles_x * tiles_y, ngroups, B);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, in, w, bias, out, Hin, Hin, tiles_x, Hf, Wf, t0, tstep,
-                       item0, n_tiles, tl ? *tl : dummy);
+    const int nwork = (Hin / 32) * (Hin / 32) * B;
+    static int per_cu = 0;                      // resident workgroups per CU for this kernel (registers + LDS)
+    if (per_cu == 0) {
+        int n = 0;
+        AXT_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)kern, 256, lds));
+        per_cu = n < 1 ? 1 : (n > 8 ? 8 : n);
+    }
+    hipLaunchKernelGGL(kern, dim3(persistent_grid(nwork, per_cu)), dim3(256), lds, st, in, w, bias, out, Hin, B, Hf, Wf,
+                       t0, tstep, item0, n_tiles, tl ? *tl : dummy);
     AXT_LAUNCH_CHECK();
     return AXT_OK;
 }
@@ -498,34 +706,42 @@ int launch_reduce(const float *slab, int S, int M, int N, int Nout, const float 
     return AXT_OK;
 }
 
-// layers 0..4 (large activations) for up to kChunkA items
-int run_front(axt_detector *d, const float *frames, int Hf, int Wf, int t0, int tstep, int item0, int n_tiles,
-              const TileList &tl, int nb, float *act4_out, hipStream_t st)
+// conv blocks 0..2 for up to kChunkA items: frames -> d_act[2] slot `slot0`
+int run_front_a(axt_detector *d, const float *frames, int Hf, int Wf, int t0, int tstep, int item0, int n_tiles,
+                const TileList &tl, int nb, int slot0, hipStream_t st)
 {
     int rc;
     {
         ProfSpan ps(d, st, 0, nb);
-        if ((rc = launch_conv<5, 20, 2, false, 8, 4, 2, true>(frames, d->d_wconv[0], d->d_bconv[0], d->d_act[0], 512, 1,
-                                                              nb, st, Hf, Wf, t0, tstep, item0, n_tiles, &tl))) return rc;
+        if ((rc = launch_conv_s2<5, 20, 5, 2, true, 4>(frames, d->d_wconv[0], d->d_bconv[0], d->d_act[0], 512, nb, st, Hf, Wf,
+                                                    t0, tstep, item0, n_tiles, &tl))) return rc;
     }
     {
         ProfSpan ps(d, st, 1, nb);
-        if ((rc = launch_conv<20, 40, 2, false, 4, 4, 3, false>(d->d_act[0], d->d_wconv[1], d->d_bconv[1], d->d_act[1],
-                                                                256, 1, nb, st))) return rc;
+        if ((rc = launch_conv_s2<20, 40, 5, 3, false, 3>(d->d_act[0], d->d_wconv[1], d->d_bconv[1], d->d_act[1], 256, nb,
+                                                      st))) return rc;
     }
     {
         ProfSpan ps(d, st, 2, nb);
-        if ((rc = launch_conv<40, 80, 1, true, 8, 4, 5, false>(d->d_act[1], d->d_wconv[2], d->d_bconv[2], d->d_act[2],
-                                                               128, 1, nb, st))) return rc;
+        if ((rc = launch_conv<40, 80, true, 8, 5>(d->d_act[1], d->d_wconv[2], d->d_bconv[2],
+                                                               d->d_act[2] + (size_t)slot0 * 80 * 64 * 64, 128, 1, nb,
+                                                               st))) return rc;
     }
+    return AXT_OK;
+}
+
+// conv blocks 3..4 for up to kChunkB items: d_act[2] -> act4_out
+int run_front_b(axt_detector *d, int nb, float *act4_out, hipStream_t st)
+{
+    int rc;
     {
         ProfSpan ps(d, st, 3, nb);
-        if ((rc = launch_conv<80, 80, 1, false, 8, 4, 5, false>(d->d_act[2], d->d_wconv[3], d->d_bconv[3], d->d_act[3],
+        if ((rc = launch_conv<80, 80, false, 8, 5>(d->d_act[2], d->d_wconv[3], d->d_bconv[3], d->d_act[3],
                                                                 64, 1, nb, st))) return rc;
     }
     {
         ProfSpan ps(d, st, 4, nb);
-        if ((rc = launch_conv<80, 80, 1, true, 8, 4, 5, false>(d->d_act[3], d->d_wconv[4], d->d_bconv[4], act4_out, 64,
+        if ((rc = launch_conv<80, 80, true, 8, 5>(d->d_act[3], d->d_wconv[4], d->d_bconv[4], act4_out, 64,
                                                                1, nb, st))) return rc;
     }
     return AXT_OK;
@@ -537,17 +753,17 @@ int run_back(axt_detector *d, int nb, float *d_yolo, hipStream_t st)
     int rc;
     {
         ProfSpan ps(d, st, 5, nb);
-        if ((rc = launch_conv<80, 80, 1, false, 8, 4, 5, false>(d->d_act[4], d->d_wconv[5], d->d_bconv[5], d->d_act[5],
+        if ((rc = launch_conv<80, 80, false, 8, 5>(d->d_act[4], d->d_wconv[5], d->d_bconv[5], d->d_act[5],
                                                                 32, 1, nb, st))) return rc;
     }
     {
         ProfSpan ps(d, st, 6, nb);
-        if ((rc = launch_conv<80, 80, 1, true, 8, 4, 5, false>(d->d_act[5], d->d_wconv[6], d->d_bconv[6], d->d_act[6],
+        if ((rc = launch_conv<80, 80, true, 8, 5>(d->d_act[5], d->d_wconv[6], d->d_bconv[6], d->d_act[6],
                                                                32, 1, nb, st))) return rc;
     }
     {
         ProfSpan ps(d, st, 7, nb);
-        if ((rc = launch_conv<80, 160, 1, false, 8, 4, 5, false>(d->d_act[6], d->d_wconv[7], d->d_bconv[7], d->d_act[7],
+        if ((rc = launch_conv<80, 160, false, 8, 5>(d->d_act[6], d->d_wconv[7], d->d_bconv[7], d->d_act[7],
                                                                  16, 2, nb, st))) return rc;
     }
     {
@@ -582,10 +798,14 @@ int forward_items(axt_detector *d, const float *frames, int Hf, int Wf, int t0, 
 {
     for (int base = 0; base < n_items; base += d->max_batch) {
         const int nb = (n_items - base < d->max_batch) ? n_items - base : d->max_batch;
-        for (int c = 0; c < nb; c += kChunkA) {
-            const int nc = (nb - c < kChunkA) ? nb - c : kChunkA;
-            const int rc = run_front(d, frames, Hf, Wf, t0, tstep, base + c, n_tiles, tl, nc,
-                                     d->d_act[4] + (size_t)c * 80 * 32 * 32, st);
+        for (int cb = 0; cb < nb; cb += kChunkB) {
+            const int nbb = (nb - cb < kChunkB) ? nb - cb : kChunkB;
+            for (int c = 0; c < nbb; c += kChunkA) {
+                const int nc = (nbb - c < kChunkA) ? nbb - c : kChunkA;
+                const int rc = run_front_a(d, frames, Hf, Wf, t0, tstep, base + cb + c, n_tiles, tl, nc, c, st);
+                if (rc) return rc;
+            }
+            const int rc = run_front_b(d, nbb, d->d_act[4] + (size_t)cb * 80 * 32 * 32, st);
             if (rc) return rc;
         }
         const int rc = run_back(d, nb, d_yolo + (size_t)base * kOut, st);
@@ -650,7 +870,7 @@ int axt_detector_create(const float *const *h_tensors, int n_tensors, int max_ba
     const size_t per_item[8] = {20u * 256 * 256, 40u * 128 * 128, 80u * 64 * 64, 80u * 64 * 64,
                                 80u * 32 * 32,   80u * 32 * 32,   80u * 16 * 16, 160u * 16 * 16};
     for (int i = 0; i < 8 && !rc; ++i)
-        rc = dev_alloc(d, &d->d_act[i], per_item[i] * (size_t)(i < 4 ? kChunkA : max_batch));
+        rc = dev_alloc(d, &d->d_act[i], per_item[i] * (size_t)(i < 2 ? kChunkA : i < 4 ? kChunkB : max_batch));
     if (!rc) rc = dev_alloc(d, &d->d_slab, (size_t)kFc1Split * max_batch * kFc);
     if (!rc) rc = dev_alloc(d, &d->d_fc1, (size_t)max_batch * kFc);
     if (!rc) rc = dev_alloc(d, &d->d_fc2, (size_t)max_batch * kFc);

@@ -15,14 +15,15 @@ struct TileOrigins { int n; short yx[2 * 256]; };
 
 // ------------------------------------------------------------------------------------------------
 // tile occupancy: occ[tile] = any(frames[:, tile] > 0)        (Timelapse.py:551-558)
-// grid: (row groups of 8, T_all); block: 256 threads striding over x. A block returns at once when every
+// grid: (row groups of 64, T_all); block: 256 threads striding over x. A block returns at once when every
 // tile of its tile row is already known to be occupied, so after the first few frames the scan costs nothing
 // (in real data nearly every tile is occupied); the worst case reads the timelapse once.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void tile_occupancy_kernel(const float *__restrict__ frames, int H, int W, int ntx,
                                                              unsigned int *__restrict__ occ_words)
 {
-    const int y0 = blockIdx.x * 8, t = blockIdx.y;
+    constexpr int ROWS = 64;
+    const int y0 = blockIdx.x * ROWS, t = blockIdx.y;
     const int ty = y0 / AXT_TILE;
     volatile unsigned int *occ = occ_words + ty * ntx;
     __shared__ int todo;
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(256) void tile_occupancy_kernel(const float *__rest
         if (occ[tx]) continue;                       // racy read: a stale 0 only costs a redundant scan
         const int x0 = tx * AXT_TILE, x1 = min(W, x0 + AXT_TILE);
         int any = 0;
-        for (int r = 0; r < 8 && y0 + r < H; ++r) {
+        for (int r = 0; r < ROWS && y0 + r < H; ++r) {
             const float *row = frames + ((long)t * H + y0 + r) * W;
             for (int x = x0 + threadIdx.x; x < x1; x += 256) any |= (row[x] > 0.f);
         }
@@ -176,7 +177,7 @@ int axt_tile_occupancy(const float *d_frames, int T_all, int H, int W, uint8_t *
     unsigned int *words = nullptr;
     AXT_CHECK_HIP(hipMallocAsync((void **)&words, sizeof(unsigned int) * nty * ntx, st));
     AXT_CHECK_HIP(hipMemsetAsync(words, 0, sizeof(unsigned int) * nty * ntx, st));
-    hipLaunchKernelGGL(tile_occupancy_kernel, dim3(axt_cdiv(H, 8), T_all), dim3(256), 0, st, d_frames, H, W, ntx, words);
+    hipLaunchKernelGGL(tile_occupancy_kernel, dim3(axt_cdiv(H, 64), T_all), dim3(256), 0, st, d_frames, H, W, ntx, words);
     AXT_LAUNCH_CHECK();
     hipLaunchKernelGGL(occ_words_to_bytes, dim3(axt_cdiv(nty * ntx, 256)), dim3(256), 0, st, words, d_occ, nty * ntx);
     AXT_LAUNCH_CHECK();

@@ -74,7 +74,9 @@ __global__ __launch_bounds__(64) void hungarian_pair_kernel(
     int *pred = col4row + cap;                          // [cap]
     int *sr = pred + cap;                               // [cap] rows scanned in this search
     int *xs = sr + cap, *ys = xs + cap;                 // [cap] column anchors
-    unsigned char *in_sc = reinterpret_cast<unsigned char *>(ys + cap);       // [cap]
+    int *xr = ys + cap, *yr = xr + cap;                 // [cap] row anchors
+    long *lunits = reinterpret_cast<long *>(yr + cap + (cap & 1));            // [dmax+1] cost table of this gap
+    unsigned char *in_sc = reinterpret_cast<unsigned char *>(lunits + dmax + 1);   // [cap]
     unsigned char *col_ok = in_sc + cap;                // [cap] column takes part
 
     const long a0 = frame_off[t], b0 = frame_off[tb];
@@ -88,7 +90,10 @@ __global__ __launch_bounds__(64) void hungarian_pair_kernel(
     for (int i = lane; i < n; i += 64) {
         u[i] = 0;
         col4row[i] = -1;
+        xr[i] = x[(long)t * cap + i];
+        yr[i] = y[(long)t * cap + i];
     }
+    for (int d = lane; d <= dmax; d += 64) lunits[d] = units[d];
     __syncthreads();
 
     for (int i = 0; i < n; ++i) {
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(64) void hungarian_pair_kernel(
             const long ucur = u[cur];
             const long rd = minVal + h_arc_cost_int(thr_units, 1, a0 + cur, 0) - ucur;
             if (rd < best_dummy) { best_dummy = rd; dummy_row = cur; }
-            const int xa = x[(long)t * cap + cur], ya = y[(long)t * cap + cur];
+            const int xa = xr[cur], ya = yr[cur];
             long bkey = HINF;
             int bidx = 0x7fffffff;
             for (int j = lane; j < m; j += 64) {
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(64) void hungarian_pair_kernel(
                 const int d = h_path_len_open(xa, ya, xs[j], ys[j], H, W, max_dist, conn8);
                 long s = spc[j];
                 if (d <= dmax) {
-                    const long c = h_arc_cost_int(units[d], 3, a0 + cur, b0 + j);
+                    const long c = h_arc_cost_int(lunits[d], 3, a0 + cur, b0 + j);
                     const long r = minVal + c - ucur - v[j];
                     if (r < s) { s = r; spc[j] = r; pred[j] = cur; }
                 }
@@ -157,49 +162,67 @@ __global__ __launch_bounds__(64) void hungarian_pair_kernel(
     for (int j = lane; j < m; j += 64) pred_out[(long)tb * cap + j] = row4col[j];
 }
 
-// chains -> track ids, numbered by (first frame, index). One block, frames in order.
-__global__ __launch_bounds__(1024) void chain_ids_kernel(const int *__restrict__ count, int n_frames, int cap,
-                                                         const int *__restrict__ pred1, const int *__restrict__ pred2,
-                                                         int *__restrict__ track, int *__restrict__ n_tracks)
+// chains -> track ids, numbered by (first frame, index), in parallel:
+//   root[k]  = first detection of k's chain, by pointer doubling over the predecessor links (ceil(log2 F) rounds);
+//   id[root] = rank of the root among all roots in slot order (one block-wide scan over the slots).
+__global__ void chain_init_kernel(const int *__restrict__ count, int n_frames, int cap, const int *__restrict__ pred1,
+                                  const int *__restrict__ pred2, int *__restrict__ root)
 {
-    __shared__ int next_id;
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= (long)n_frames * cap) return;
+    const int t = s / cap, i = s - (long)t * cap;
+    int r = -1;                                           // slots beyond count
+    if (i < min(count[t], cap)) {
+        const int p1 = (t >= 1) ? pred1[s] : -1;
+        const int p2 = (t >= 2) ? pred2[s] : -1;
+        r = (p1 >= 0) ? (t - 1) * cap + p1 : (p2 >= 0) ? (t - 2) * cap + p2 : (int)s;
+    }
+    root[s] = r;
+}
+
+__global__ void chain_jump_kernel(const int *__restrict__ in, int *__restrict__ out, long n)
+{
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int r = in[s];
+    out[s] = (r < 0) ? -1 : in[r];
+}
+
+// ids of roots = exclusive prefix count of (root[s] == s) in slot order; single block, chunked scan
+__global__ __launch_bounds__(1024) void chain_rank_kernel(const int *__restrict__ root, long n, int *__restrict__ rank,
+                                                          int *__restrict__ n_tracks)
+{
     __shared__ int wtot[16];
-    if (threadIdx.x == 0) next_id = 0;
+    __shared__ int base;
+    if (threadIdx.x == 0) base = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int t = 0; t < n_frames; ++t) {
-        const int n = min(count[t], cap);
-        for (int i0 = 0; i0 < n; i0 += 1024) {
-            const int i = i0 + threadIdx.x;
-            int id = -1;
-            bool fresh = false;
-            if (i < n) {
-                const int p1 = (t >= 1) ? pred1[(long)t * cap + i] : -1;
-                const int p2 = (t >= 2) ? pred2[(long)t * cap + i] : -1;
-                if (p1 >= 0) id = track[(long)(t - 1) * cap + p1];
-                else if (p2 >= 0) id = track[(long)(t - 2) * cap + p2];
-                else fresh = true;
-            }
-            const unsigned long long mk = __ballot(fresh);
-            if (lane == 0) wtot[wave] = __popcll(mk);
-            __syncthreads();
-            int off = next_id;
-            for (int w = 0; w < wave; ++w) off += wtot[w];
-            if (fresh) id = off + __popcll(mk & ((1ull << lane) - 1ull));
-            if (i < n) track[(long)t * cap + i] = id;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                int s = 0;
-                for (int w = 0; w < 16; ++w) s += wtot[w];
-                next_id += s;
-            }
-            __syncthreads();
+    for (long s0 = 0; s0 < n; s0 += 1024) {
+        const long s = s0 + threadIdx.x;
+        const bool is_root = s < n && root[s] == (int)s;
+        const unsigned long long mk = __ballot(is_root);
+        if (lane == 0) wtot[wave] = __popcll(mk);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wtot[w];
+        if (is_root) rank[s] = off + __popcll(mk & ((1ull << lane) - 1ull));
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tot = 0;
+            for (int w = 0; w < 16; ++w) tot += wtot[w];
+            base += tot;
         }
-        for (int i = n + threadIdx.x; i < cap; i += 1024) track[(long)t * cap + i] = -1;
-        __threadfence_block();
         __syncthreads();
     }
-    if (threadIdx.x == 0) *n_tracks = next_id;
+    if (threadIdx.x == 0) *n_tracks = base;
+}
+
+__global__ void chain_assign_kernel(const int *__restrict__ root, const int *__restrict__ rank, int *__restrict__ track, long n)
+{
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int r = root[s];
+    track[s] = (r < 0) ? -1 : rank[r];
 }
 
 __global__ void fill_int_kernel(int *p, long n, int v)
@@ -229,11 +252,12 @@ extern "C" int axt_hungarian_assoc(const int32_t *d_x, const int32_t *d_y, const
     AXT_LAUNCH_CHECK();
     int rc = axt_frame_offsets(d_count, n_frames, cap, frame_off, st);
     if (rc) return rc;
-    const size_t lds = (size_t)cap * (3 * 8 + 6 * 4 + 2);
+    const size_t lds = (size_t)cap * (3 * 8 + 8 * 4 + 2) + 8 + (size_t)(max_dist + 2) * 8;
+    AXT_REQUIRE(lds <= 160 * 1024, "axt_hungarian_assoc: cap %d needs %zu bytes of LDS", cap, lds);
     static bool attr = false;
     if (!attr) {
-        AXT_CHECK_HIP(hipFuncSetAttribute((const void *)hungarian_pair_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2048 * 50));
-        AXT_CHECK_HIP(hipFuncSetAttribute((const void *)hungarian_pair_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2048 * 50));
+        AXT_CHECK_HIP(hipFuncSetAttribute((const void *)hungarian_pair_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        AXT_CHECK_HIP(hipFuncSetAttribute((const void *)hungarian_pair_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
     if (n_frames > 1) {
@@ -249,8 +273,20 @@ extern "C" int axt_hungarian_assoc(const int32_t *d_x, const int32_t *d_y, const
                            (const int *)pred1, succ2, pred2);
         AXT_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(chain_ids_kernel, dim3(1), dim3(1024), 0, st, d_count, n_frames, cap, (const int *)pred1,
-                       (const int *)pred2, d_track, d_n_tracks);
+    // chain numbering: succ1/succ2 are no longer needed and serve as ping-pong buffers
+    const unsigned nb = (unsigned)((slots + 255) / 256);
+    int *ra = succ1, *rb = succ2;
+    hipLaunchKernelGGL(chain_init_kernel, dim3(nb), dim3(256), 0, st, d_count, n_frames, cap, (const int *)pred1,
+                       (const int *)pred2, ra);
+    AXT_LAUNCH_CHECK();
+    for (int span = 1; span < n_frames; span *= 2) {
+        hipLaunchKernelGGL(chain_jump_kernel, dim3(nb), dim3(256), 0, st, (const int *)ra, rb, slots);
+        AXT_LAUNCH_CHECK();
+        int *tmp = ra; ra = rb; rb = tmp;
+    }
+    hipLaunchKernelGGL(chain_rank_kernel, dim3(1), dim3(1024), 0, st, (const int *)ra, slots, rb, d_n_tracks);
+    AXT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(chain_assign_kernel, dim3(nb), dim3(256), 0, st, (const int *)ra, (const int *)rb, d_track, slots);
     AXT_LAUNCH_CHECK();
     return AXT_OK;
 }
