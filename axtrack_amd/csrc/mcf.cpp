@@ -155,14 +155,82 @@ struct Lsap {
     int n;
     const int64_t *obs, *entry, *exitc, *row_ptr, *cost;
     const int32_t *col;
-    std::vector<int64_t> u, v;             // duals of rows / columns
-    std::vector<int32_t> col4row, row4col; // matching
-    std::vector<int32_t> arc4row;          // transition arc used by row (or -1)
+    std::vector<int64_t> u, v;              // duals of rows / columns
+    std::vector<int32_t> col4row, row4col;  // matching
+    std::vector<int32_t> arc4row;           // transition arc used by row (or -1)
     // per-search scratch, reset through the touched lists
-    std::vector<int64_t> spc;              // shortest path cost to a column
+    std::vector<int64_t> spc;               // shortest path cost to a column
     std::vector<int32_t> pred_row, pred_arc;
     std::vector<uint8_t> in_sc;
     std::vector<int32_t> touched_cols, sr_rows;
+    std::vector<std::pair<int64_t, int32_t>> heap;   // binary min-heap of (key, column), storage reused
+    size_t stat_rows = 0, stat_cols = 0;
+
+    void insert_row(int i)
+    {
+        typedef std::pair<int64_t, int32_t> Item;
+        heap.clear();
+        int64_t minVal = 0;
+        int cur = i, sink = -1;
+        sr_rows.clear();
+        while (sink < 0) {
+            sr_rows.push_back(cur);
+            const int64_t ucur = u[cur];
+            auto relax = [&](int j, int64_t c, int32_t arc) {
+                if (in_sc[j]) return;
+                const int64_t r = minVal + c - ucur - v[j];
+                if (r < spc[j]) {
+                    if (spc[j] == INF) touched_cols.push_back(j);
+                    spc[j] = r;
+                    pred_row[j] = cur;
+                    pred_arc[j] = arc;
+                    heap.emplace_back(r, j);
+                    std::push_heap(heap.begin(), heap.end(), std::greater<Item>());
+                }
+            };
+            relax(cur, 0, -1);                                               // stay unused
+            relax(n + cur, obs[cur] + entry[cur] + exitc[cur], -1);          // a track of its own / track end
+            const int64_t base = obs[cur] + entry[cur];
+            for (int64_t e = row_ptr[cur]; e < row_ptr[cur + 1]; ++e)
+                relax(col[e], base + cost[e] - entry[col[e]], (int32_t)e);   // k -> b, b's entry refunded
+            int j = -1;
+            while (!heap.empty()) {
+                std::pop_heap(heap.begin(), heap.end(), std::greater<Item>());
+                const Item it = heap.back();
+                heap.pop_back();
+                if (in_sc[it.second] || it.first > spc[it.second]) continue;
+                j = it.second;
+                minVal = it.first;
+                break;
+            }
+            in_sc[j] = 1;                    // X_i is always reachable, so a column is always found
+            if (row4col[j] < 0) sink = j;
+            else cur = row4col[j];
+        }
+        // dual update (Crouse 2016, Alg. 1); unmatched columns keep v = 0, as the rectangular dual requires
+        u[i] += minVal;
+        for (size_t k = 1; k < sr_rows.size(); ++k) {
+            const int r = sr_rows[k];
+            u[r] += minVal - spc[col4row[r]];
+        }
+        for (int32_t j : touched_cols)
+            if (in_sc[j]) v[j] -= minVal - spc[j];
+        // augment
+        int j = sink;
+        for (;;) {
+            const int r = pred_row[j];
+            row4col[j] = r;
+            const int prev = col4row[r];
+            col4row[r] = j;
+            arc4row[r] = pred_arc[j];
+            if (r == i) break;
+            j = prev;
+        }
+        stat_rows += sr_rows.size();
+        stat_cols += touched_cols.size();
+        for (int32_t c : touched_cols) { spc[c] = INF; in_sc[c] = 0; }
+        touched_cols.clear();
+    }
 
     void run()
     {
@@ -175,71 +243,10 @@ struct Lsap {
         pred_row.assign(2 * (size_t)n, -1);
         pred_arc.assign(2 * (size_t)n, -1);
         in_sc.assign(2 * (size_t)n, 0);
-        typedef std::pair<int64_t, int32_t> Item;
-        std::priority_queue<Item, std::vector<Item>, std::greater<Item>> pq;
-        for (int i = 0; i < n; ++i) {
-            while (!pq.empty()) pq.pop();
-            int64_t minVal = 0;
-            int cur = i, sink = -1;
-            sr_rows.clear();
-            while (sink < 0) {
-                sr_rows.push_back(cur);
-                auto relax = [&](int j, int64_t c, int32_t arc) {
-                    if (in_sc[j]) return;
-                    const int64_t r = minVal + c - u[cur] - v[j];
-                    if (r < spc[j]) {
-                        if (spc[j] == INF) touched_cols.push_back(j);
-                        spc[j] = r;
-                        pred_row[j] = cur;
-                        pred_arc[j] = arc;
-                        pq.push(Item(r, j));
-                    }
-                };
-                relax(cur, 0, -1);                                               // stay unused
-                relax(n + cur, obs[cur] + entry[cur] + exitc[cur], -1);          // a track of its own / track end
-                const int64_t base = obs[cur] + entry[cur];
-                for (int64_t e = row_ptr[cur]; e < row_ptr[cur + 1]; ++e)
-                    relax(col[e], base + cost[e] - entry[col[e]], (int32_t)e);   // k -> b, b's entry refunded
-                int j = -1;
-                while (!pq.empty()) {
-                    const Item it = pq.top();
-                    pq.pop();
-                    if (in_sc[it.second] || it.first > spc[it.second]) continue;
-                    j = it.second;
-                    minVal = it.first;
-                    break;
-                }
-                // X_i is always reachable, so a column is always found
-                in_sc[j] = 1;
-                if (row4col[j] < 0) sink = j;
-                else cur = row4col[j];
-            }
-            // dual update (Crouse 2016, Alg. 1)
-            u[i] += minVal;
-            for (size_t k = 1; k < sr_rows.size(); ++k) {
-                const int r = sr_rows[k];
-                u[r] += minVal - spc[col4row[r]];
-            }
-            for (int32_t j : touched_cols)
-                if (in_sc[j]) v[j] -= minVal - spc[j];
-            // augment
-            int j = sink;
-            for (;;) {
-                const int r = pred_row[j];
-                row4col[j] = r;
-                const int prev = col4row[r];
-                col4row[r] = j;
-                arc4row[r] = pred_arc[j];
-                if (r == i) break;
-                j = prev;
-            }
-            dbg_rows += sr_rows.size(); dbg_cols += touched_cols.size(); if (sr_rows.size() > dbg_max) dbg_max = sr_rows.size();
-            for (int32_t c : touched_cols) { spc[c] = INF; in_sc[c] = 0; }
-            touched_cols.clear();
-        }
-        if (getenv("AXT_MCF_DEBUG")) fprintf(stderr, "lsap: n=%d rows scanned=%zu cols touched=%zu max SR=%zu\n", n, dbg_rows, dbg_cols, dbg_max);
+        for (int i = 0; i < n; ++i) insert_row(i);
+        if (getenv("AXT_MCF_DEBUG"))
+            fprintf(stderr, "lsap: n=%d rows scanned=%zu cols touched=%zu\n", n, stat_rows, stat_cols);
     }
-    size_t dbg_rows = 0, dbg_cols = 0, dbg_max = 0;
 };
 
 }  // namespace

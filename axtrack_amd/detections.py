@@ -366,23 +366,44 @@ class AxonDetections(object):
         column_position//3, so frames after one without IDed detections are labelled one too low."""
         F = len(self)
         frame, tid, conf, x, y = self.ided_arrays()
-        ids = np.unique(tid)
-        row = np.searchsorted(ids, tid)
-        present = np.zeros(F, bool)
-        present[frame] = True
+        n_ids = int(tid.max()) + 1 if len(tid) else 0
+        if len(tid) and np.bincount(tid, minlength=n_ids).min() == 0:
+            ids = np.unique(tid)                               # ids with gaps (adopted from a cache)
+            row = np.searchsorted(ids, tid)
+        else:
+            ids, row = np.arange(n_ids), tid
         if self.reproduce_label_quirk:
+            present = np.zeros(F, bool)
+            present[frame] = True
             slot_of_frame = np.cumsum(present) - 1          # frames without IDs vanish from the concat (:831)
         else:
             slot_of_frame = np.arange(F)
         vals = np.full((len(ids), 3 * F), np.nan)
-        s = slot_of_frame[frame]
-        vals[row, 3 * s + 0] = x
-        vals[row, 3 * s + 1] = y
-        vals[row, 3 * s + 2] = conf.astype(np.float64)
-        cols = pd.MultiIndex.from_product([range(F), ['anchor_x', 'anchor_y', 'conf']], names=('frameID', 'detInfo'))
-        df = pd.DataFrame(vals, index=[f'Axon_{i:0>3}' for i in ids], columns=cols)
-        df.index.rename('axonID', inplace=True)
+        s = 3 * slot_of_frame[frame]
+        vals[row, s] = x
+        vals[row, s + 1] = y
+        vals[row, s + 2] = conf
+        df = pd.DataFrame(vals, index=_axon_index(ids), columns=_ided_columns(F), copy=False)
         return df
+
+
+_COLUMNS_CACHE = {}
+
+
+def _ided_columns(F):
+    """MultiIndex (frameID, detInfo) of IDed_dets_all; building it costs more than the rest of the table."""
+    if F not in _COLUMNS_CACHE:
+        _COLUMNS_CACHE[F] = pd.MultiIndex.from_product([range(F), ['anchor_x', 'anchor_y', 'conf']],
+                                                       names=('frameID', 'detInfo'))
+    return _COLUMNS_CACHE[F]
+
+
+_AXON_NAMES = [f'Axon_{i:0>3}' for i in range(2048)]
+
+
+def _axon_index(ids):
+    names = [_AXON_NAMES[i] if i < 2048 else f'Axon_{i:0>3}' for i in ids]
+    return pd.Index(names, name='axonID')
 
 
 def _splitmix64(x):
