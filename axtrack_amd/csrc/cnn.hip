@@ -59,8 +59,20 @@ __device__ __forceinline__ WorkRange my_work(int nwork)
 
 // epilogue shared by the conv kernels: + folded bias, LeakyReLU(0.1), optional 2x2 max, store NCHW.
 // acc[m][n][j]: pixel (row y0 + wave*MT + m, x0 + q*4 + j), channel grp*NT*16 + n*16 + p.
+// The lane's NT bias values are loaded once, before the main loop: a load here would make the compiler drain
+// the vector-memory queue (prefetches and earlier stores included) in every epilogue.
+template <int COUT, int NT>
+__device__ __forceinline__ void load_bias(const float *__restrict__ bias, int grp, int p, float (&bias_v)[NT])
+{
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int ch = grp * NT * 16 + n * 16 + p;
+        bias_v[n] = bias[ch < COUT ? ch : 0];
+    }
+}
+
 template <int COUT, bool POOL, int MT, int NT>
-__device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[MT][NT], const float *__restrict__ bias,
+__device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[MT][NT], const float (&bias_v)[NT],
                                               float *__restrict__ out, int b, int grp, int y0, int x0, int wave, int p,
                                               int q, int Hout, int Wout)
 {
@@ -68,7 +80,7 @@ __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[MT][NT], const 
     for (int n = 0; n < NT; ++n) {
         const int ch = grp * NT * 16 + n * 16 + p;
         if (ch >= COUT) continue;
-        const float bv = bias[ch];
+        const float bv = bias_v[n];
         float *och = out + ((long)b * COUT + ch) * Hout * Wout;
         if constexpr (!POOL) {
 #pragma unroll
@@ -184,10 +196,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(
     auto load_chunk = [&](int chunk) {
         const float *csrc = isrc + (long)chunk * CCH * cstride;
 #pragma unroll
-        for (int k = 0; k < NPE; ++k) {
-            const float v = csrc[goff[k] < 0 ? 0 : goff[k]];
-            pv[k] = goff[k] < 0 ? 0.f : v;
-        }
+        for (int k = 0; k < NPE; ++k) pv[k] = csrc[goff[k] < 0 ? 0 : goff[k]];     // masked at store time
         const f32x4 *w4 = reinterpret_cast<const f32x4 *>(wsrc + (long)chunk * KROWS * NPADW);
 #pragma unroll
         for (int k = 0; k < NWE; ++k) {
@@ -197,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(
     };
     auto store_chunk = [&]() {
 #pragma unroll
-        for (int k = 0; k < NPE; ++k) patch[loff[k]] = pv[k];
+        for (int k = 0; k < NPE; ++k) patch[loff[k]] = goff[k] < 0 ? 0.f : pv[k];
         f32x4 *l4 = reinterpret_cast<f32x4 *>(wl);
 #pragma unroll
         for (int k = 0; k < NWE; ++k) {
@@ -205,6 +214,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(
             if (NW4 % 256 == 0 || k + 1 < NWE || e < NW4) l4[e] = wv[k];
         }
     };
+    float bias_v[NT];
+    load_bias<COUT, NT>(bias, grp, p, bias_v);
 
     const int a_base = q * PLANE + (wave * MT) * PW + p;
     const int b_base = q * NPADW + p;
@@ -238,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bw[n], acc[m][n], 0, 0, 0);
         }
     }
-    conv_epilogue<COUT, POOL, MT, NT>(acc, bias, out, b, grp, y0, x0, wave, p, q, Hout, Hout);
+    conv_epilogue<COUT, POOL, MT, NT>(acc, bias_v, out, b, grp, y0, x0, wave, p, q, Hout, Hout);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -352,12 +363,13 @@ __global__ __launch_bounds__(256) void conv3x3_s2_mfma(
     };
     auto load_chunk = [&](int chunk) {       // loads (nxt item or current item: the plan in goff/gx0), chunk
         const float *csrc = in + nxt_src + (long)chunk * NPC * nxt_cstride;
+        // raw loads from clamped addresses; the zero mask is applied in store_chunk, so that nothing consumes
+        // the loaded registers (and forces a wait) before the MFMAs of the current step have been issued
         if (nxt_aligned) {
 #pragma unroll
             for (int k = 0; k < NPE; ++k) {
                 const bool ok = gx0[k] >= 0 && gx0[k] + 3 < nxt_limx;
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(csrc + (ok ? goff[k] : 0));
-                pv[k] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+                pv[k] = *reinterpret_cast<const f32x4 *>(csrc + (ok ? goff[k] : 0));
             }
         } else {
 #pragma unroll
@@ -366,17 +378,28 @@ __global__ __launch_bounds__(256) void conv3x3_s2_mfma(
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const bool ok = gx0[k] + j >= 0 && gx0[k] + j < nxt_limx;
-                    const float t = csrc[ok ? goff[k] + j : 0];
-                    v[j] = ok ? t : 0.f;
+                    v[j] = csrc[ok ? goff[k] + j : 0];
                 }
                 pv[k] = v;
             }
         }
     };
-    auto store_chunk = [&]() {
+    auto store_chunk = [&]() {          // masks refer to the plan the registers were loaded with (still current)
 #pragma unroll
-        for (int k = 0; k < NPE; ++k) *reinterpret_cast<f32x4 *>(patch + loff[k]) = pv[k];
+        for (int k = 0; k < NPE; ++k) {
+            f32x4 v = pv[k];
+            if (nxt_aligned) {
+                if (!(gx0[k] >= 0 && gx0[k] + 3 < nxt_limx)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (!(gx0[k] + j >= 0 && gx0[k] + j < nxt_limx)) v[j] = 0.f;
+            }
+            *reinterpret_cast<f32x4 *>(patch + loff[k]) = v;
+        }
     };
+    float bias_v[NT];
+    load_bias<COUT, NT>(bias, 0, p, bias_v);
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -419,7 +442,7 @@ __global__ __launch_bounds__(256) void conv3x3_s2_mfma(
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bw[n], acc[m][n], 0, 0, 0);
         }
         if (last_chunk) {
-            conv_epilogue<COUT, false, MT, NT>(acc, bias, out, cur_b, 0, cur_y0, cur_x0, wave, p, q, Hout, Hout);
+            conv_epilogue<COUT, false, MT, NT>(acc, bias_v, out, cur_b, 0, cur_y0, cur_x0, wave, p, q, Hout, Hout);
             if (!has_next) break;
 #pragma unroll
             for (int m = 0; m < MT; ++m)
