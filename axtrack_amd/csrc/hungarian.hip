@@ -60,7 +60,7 @@ __global__ __launch_bounds__(64) void hungarian_pair_kernel(
     const int *__restrict__ frame_off, int n_frames, int cap, int H, int W, int max_dist, int conn8,
     int dmax, const long *__restrict__ units, long thr_units,
     const int *__restrict__ succ1, const int *__restrict__ pred1,
-    int *__restrict__ succ_out, int *__restrict__ pred_out)
+    int *__restrict__ succ_out, int *__restrict__ pred_out, int cdim)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
     const int t = blockIdx.x, tb = t + GAP, lane = threadIdx.x;
@@ -76,8 +76,10 @@ __global__ __launch_bounds__(64) void hungarian_pair_kernel(
     int *xs = sr + cap, *ys = xs + cap;                 // [cap] column anchors
     int *xr = ys + cap, *yr = xr + cap;                 // [cap] row anchors
     long *lunits = reinterpret_cast<long *>(yr + cap + (cap & 1));            // [dmax+1] cost table of this gap
-    unsigned char *in_sc = reinterpret_cast<unsigned char *>(lunits + dmax + 1);   // [cap]
+    long *ccache = lunits + dmax + 1;                   // [cdim][cdim] cost matrix of the pair, if it fits
+    unsigned char *in_sc = reinterpret_cast<unsigned char *>(ccache + (long)cdim * cdim);   // [cap]
     unsigned char *col_ok = in_sc + cap;                // [cap] column takes part
+    const bool cached = n <= cdim && m <= cdim;
 
     const long a0 = frame_off[t], b0 = frame_off[tb];
     for (int j = lane; j < m; j += 64) {
@@ -96,8 +98,44 @@ __global__ __launch_bounds__(64) void hungarian_pair_kernel(
     for (int d = lane; d <= dmax; d += 64) lunits[d] = units[d];
     __syncthreads();
 
+    // cost of linking row i to column j (HINF: not admitted)
+    auto link_cost = [&](int i, int j) -> long {
+        if (!col_ok[j]) return HINF;
+        const int d = h_path_len_open(xr[i], yr[i], xs[j], ys[j], H, W, max_dist, conn8);
+        return d <= dmax ? h_arc_cost_int(lunits[d], 3, a0 + i, b0 + j) : HINF;
+    };
+
+    // ---- initialisation (Jonker-Volgenant): every row gets u = its cheapest option (a column or its own dummy),
+    // which keeps all reduced costs >= 0 with v = 0, and is assigned to that option if it is still free (tight
+    // pair). Only rows that lose such a contest need an augmenting search. Lanes work on different rows here.
+    for (int i = lane; i < n; i += 64) {
+        const bool active = (GAP == 1) || (succ1[(long)t * cap + i] < 0);
+        long best = h_arc_cost_int(thr_units, 1, a0 + i, 0);
+        int bj = -2;
+        if (active) {
+            for (int j = 0; j < m; ++j) {
+                const long c = link_cost(i, j);
+                if (cached) ccache[i * cdim + j] = c;
+                if (c < best) { best = c; bj = j; }
+            }
+        }
+        u[i] = best;
+        pred[i] = bj;                    // pred[] is free until the first search: holds the row's preferred column
+    }
+    __syncthreads();
+    if (lane == 0) {
+        for (int i = 0; i < n; ++i) {
+            if (GAP == 2 && succ1[(long)t * cap + i] >= 0) continue;
+            const int bj = pred[i];
+            if (bj == -2) col4row[i] = -2;
+            else if (row4col[bj] < 0) { row4col[bj] = i; col4row[i] = bj; }
+        }
+    }
+    __syncthreads();
+
     for (int i = 0; i < n; ++i) {
         if (GAP == 2 && succ1[(long)t * cap + i] >= 0) continue;      // wave-uniform
+        if (col4row[i] != -1) continue;                               // settled by the initialisation
         for (int j = lane; j < m; j += 64) { spc[j] = HINF; in_sc[j] = 0; }
         __syncthreads();
         long minVal = 0, best_dummy = HINF;
@@ -108,15 +146,13 @@ __global__ __launch_bounds__(64) void hungarian_pair_kernel(
             const long ucur = u[cur];
             const long rd = minVal + h_arc_cost_int(thr_units, 1, a0 + cur, 0) - ucur;
             if (rd < best_dummy) { best_dummy = rd; dummy_row = cur; }
-            const int xa = xr[cur], ya = yr[cur];
             long bkey = HINF;
             int bidx = 0x7fffffff;
             for (int j = lane; j < m; j += 64) {
                 if (in_sc[j] || !col_ok[j]) continue;
-                const int d = h_path_len_open(xa, ya, xs[j], ys[j], H, W, max_dist, conn8);
+                const long c = cached ? ccache[cur * cdim + j] : link_cost(cur, j);
                 long s = spc[j];
-                if (d <= dmax) {
-                    const long c = h_arc_cost_int(lunits[d], 3, a0 + cur, b0 + j);
+                if (c != HINF) {
                     const long r = minVal + c - ucur - v[j];
                     if (r < s) { s = r; spc[j] = r; pred[j] = cur; }
                 }
@@ -252,8 +288,12 @@ extern "C" int axt_hungarian_assoc(const int32_t *d_x, const int32_t *d_y, const
     AXT_LAUNCH_CHECK();
     int rc = axt_frame_offsets(d_count, n_frames, cap, frame_off, st);
     if (rc) return rc;
-    const size_t lds = (size_t)cap * (3 * 8 + 8 * 4 + 2) + 8 + (size_t)(max_dist + 2) * 8;
-    AXT_REQUIRE(lds <= 160 * 1024, "axt_hungarian_assoc: cap %d needs %zu bytes of LDS", cap, lds);
+    const size_t lds_base = (size_t)cap * (3 * 8 + 8 * 4 + 2) + 8 + (size_t)(max_dist + 2) * 8;
+    AXT_REQUIRE(lds_base <= 160 * 1024, "axt_hungarian_assoc: cap %d needs %zu bytes of LDS", cap, lds_base);
+    // pairs with at most cdim x cdim detections keep their cost matrix in LDS (72 KiB) instead of recomputing it
+    int cdim = cap < 96 ? cap : 96;
+    if (lds_base + (size_t)cdim * cdim * 8 > 160 * 1024) cdim = 0;
+    const size_t lds = lds_base + (size_t)cdim * cdim * 8;
     static bool attr = false;
     if (!attr) {
         AXT_CHECK_HIP(hipFuncSetAttribute((const void *)hungarian_pair_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -263,14 +303,14 @@ extern "C" int axt_hungarian_assoc(const int32_t *d_x, const int32_t *d_y, const
     if (n_frames > 1) {
         hipLaunchKernelGGL(hungarian_pair_kernel<1>, dim3(n_frames - 1), dim3(64), lds, st, d_x, d_y, d_count, frame_off,
                            n_frames, cap, H, W, max_dist, conn8, h_dmax[0], (const long *)d_cost_units, (long)thr_units,
-                           (const int *)nullptr, (const int *)nullptr, succ1, pred1);
+                           (const int *)nullptr, (const int *)nullptr, succ1, pred1, cdim);
         AXT_LAUNCH_CHECK();
     }
     if (max_gap == 2 && n_frames > 2) {
         hipLaunchKernelGGL(hungarian_pair_kernel<2>, dim3(n_frames - 2), dim3(64), lds, st, d_x, d_y, d_count, frame_off,
                            n_frames, cap, H, W, max_dist, conn8, h_dmax[1],
                            (const long *)d_cost_units + (max_dist + 1), (long)thr_units, (const int *)succ1,
-                           (const int *)pred1, succ2, pred2);
+                           (const int *)pred1, succ2, pred2, cdim);
         AXT_LAUNCH_CHECK();
     }
     // chain numbering: succ1/succ2 are no longer needed and serve as ping-pong buffers

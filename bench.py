@@ -47,6 +47,9 @@ def main():
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--cpu-frames', type=int, default=24, help='detection frames of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--no-profile', action='store_true', help='do not bracket kernels with HIP events')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='gloo only for rehearsals')
+    ap.add_argument('--single-device', action='store_true',
+                    help='rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -54,11 +57,16 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group('gloo')
 
     import axtrack_amd
     from axtrack_amd import synth, params

@@ -1,0 +1,34 @@
+"""Worker of tests/test_gpu_parity.py::test_two_rank_frame_sharding: one rank of a 2-rank (gloo) run in
+which both ranks share cuda:0 -- the same code path bench.py --gpus N takes with RCCL."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(rank, world, port, q, total_frames, seed):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import axtrack_amd
+    from axtrack_amd import synth, params, sharded
+    f0, per = sharded.frame_block(total_frames, rank, world)
+    frames = synth.synth_frames(total_frames + 4, 512, 512, seed=seed, t_range=(f0, f0 + per + 4))
+    model = axtrack_amd.Detector(synth.synth_state_dict(42), max_batch=per)
+    tl = axtrack_amd.Timelapse(frames, name='shard')
+    out = {}
+    for mode in ('hungarian', 'mcf'):
+        P = params.load_parameters()
+        P['ASSOCIATION'] = mode
+        ad = axtrack_amd.AxonDetections(model, tl, P, None)
+        ad.detect_dataset()
+        ad.gather_detections()
+        ad.assign_ids()
+        out[mode] = (ad.n_ids, ad._track_flat.tobytes(), ad.IDed_dets_all.to_numpy().tobytes())
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()

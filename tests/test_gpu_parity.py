@@ -387,3 +387,32 @@ def test_inference_with_mask_end_to_end(weights):
     ref = orc.inference(frames, weights, mask=mask, P=orc.DEFAULTS, yolo=list(yolo))
     got = tracks_from_next(np.zeros(len(ad._track_flat)), ad._track_flat, ad._offs)
     assert got == ref['trajs'] and ad.mcf_total_cost == ref['total_cost']
+
+
+# ----------------------------------------------------------------------------------------- multi-GPU path
+def test_two_rank_frame_sharding(weights):
+    """Two ranks (gloo, both on cuda:0) each detect half of the frames, all-gather the detections and run the
+    replicated association: both must equal the single-process result bit for bit, in both association modes."""
+    import socket
+    import torch.multiprocessing as mp
+    import gpu_shard_worker
+    total, seed = 16, 41
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=gpu_shard_worker.run, args=(r, 2, port, q, total, seed)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    frames = synth.synth_frames(total + 4, 512, 512, seed=seed)
+    for mode in ('hungarian', 'mcf'):
+        P = params.load_parameters()
+        P['ASSOCIATION'] = mode
+        ad = _run_inference(frames, weights, P, name='shard')
+        ref = (ad.n_ids, ad._track_flat.tobytes(), ad.IDed_dets_all.to_numpy().tobytes())
+        assert res[0][mode] == ref and res[1][mode] == ref, mode
