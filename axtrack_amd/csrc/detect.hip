@@ -20,10 +20,10 @@ struct TileOrigins { int n; short yx[2 * 256]; };
 // (in real data nearly every tile is occupied); the worst case reads the timelapse once.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void tile_occupancy_kernel(const float *__restrict__ frames, int H, int W, int ntx,
-                                                             unsigned int *__restrict__ occ_words)
+                                                             unsigned int *__restrict__ occ_words, int t_first)
 {
     constexpr int ROWS = 64;
-    const int y0 = blockIdx.x * ROWS, t = blockIdx.y;
+    const int y0 = blockIdx.x * ROWS, t = t_first + blockIdx.y;
     const int ty = y0 / AXT_TILE;
     volatile unsigned int *occ = occ_words + ty * ntx;
     __shared__ int todo;
@@ -177,8 +177,16 @@ int axt_tile_occupancy(const float *d_frames, int T_all, int H, int W, uint8_t *
     unsigned int *words = nullptr;
     AXT_CHECK_HIP(hipMallocAsync((void **)&words, sizeof(unsigned int) * nty * ntx, st));
     AXT_CHECK_HIP(hipMemsetAsync(words, 0, sizeof(unsigned int) * nty * ntx, st));
-    hipLaunchKernelGGL(tile_occupancy_kernel, dim3(axt_cdiv(H, 64), T_all), dim3(256), 0, st, d_frames, H, W, ntx, words);
+    // two launches: the first few frames usually mark every tile, and the blocks of the second launch then
+    // return at once (their early-exit test runs after the first launch has completed)
+    const int t_head = T_all < 4 ? T_all : 4;
+    hipLaunchKernelGGL(tile_occupancy_kernel, dim3(axt_cdiv(H, 64), t_head), dim3(256), 0, st, d_frames, H, W, ntx, words, 0);
     AXT_LAUNCH_CHECK();
+    if (T_all > t_head) {
+        hipLaunchKernelGGL(tile_occupancy_kernel, dim3(axt_cdiv(H, 64), T_all - t_head), dim3(256), 0, st, d_frames, H, W,
+                           ntx, words, t_head);
+        AXT_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(occ_words_to_bytes, dim3(axt_cdiv(nty * ntx, 256)), dim3(256), 0, st, words, d_occ, nty * ntx);
     AXT_LAUNCH_CHECK();
     AXT_CHECK_HIP(hipFreeAsync(words, st));

@@ -45,7 +45,7 @@ def main():
                          "'mcf' = the reference's global min-cost-flow tracker")
     ap.add_argument('--frames', type=int, default=256, help='input frames per GPU (T_all)')
     ap.add_argument('--size', type=int, default=512)
-    ap.add_argument('--cpu-frames', type=int, default=24, help='detection frames of the CPU-baseline sample (0 = skip)')
+    ap.add_argument('--cpu-frames', type=int, default=64, help='detection frames of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--no-profile', action='store_true', help='do not bracket kernels with HIP events')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='gloo only for rehearsals')
     ap.add_argument('--single-device', action='store_true',
@@ -181,7 +181,7 @@ def main():
             cnn_flops = sum(k['flops_per_tile'] * k['tiles'] for k in prof if 'reduce' not in k['name'])
             out['roofline'] = {
                 'bound': 'mfma', 'kernel': dom['name'], 'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
-                'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': committed_traffic(dom['name']),
                 'avg_launch_ms': round(dom['ms'] / max(dom['launches'], 1), 4),
                 'flops_per_launch': flops / max(dom['launches'], 1),
                 'whole_cnn': {'achieved': round(cnn_flops / (cnn_ms * 1e-3) / 1e12, 2),
@@ -197,6 +197,21 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def committed_traffic(kernel_name):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/*_traffic.json, written by profiles/summarize.py); None if no such profile matches the kernel."""
+    import glob
+    import re
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_traffic.json'))):
+        t = json.load(open(f))
+        m = re.search(r'<(\d+)->(\d+)', t.get('kernel', ''))
+        if m and f'{m.group(1)}>{m.group(2)}' in kernel_name.replace(' ', ''):
+            best = t
+    return None if best is None else {'hbm_bytes_per_launch': best['hbm_bytes_per_launch'], 'source': 'profiles/ (rocprofv3 --pmc)',
+                                      'fetch_kb_raw': best['fetch_kb_raw'], 'write_kb': best['write_kb']}
 
 
 def cpu_baseline(args, sd, synth):

@@ -2,9 +2,12 @@
 """Per-kernel averages of every counter in a rocprofv3 counter_collection.csv. usage: pmc_summary.py <csv> [filter]"""
 import csv, re, sys, collections
 def short(name):
-    m = re.search(r'conv3x3_mfma<(\d+), (\d+), (\d), (true|false)', name)
+    m = re.search(r'conv3x3_mfma<(\d+), (\d+), (true|false)', name)
     if m:
-        return f'conv<{m.group(1)}->{m.group(2)},s{m.group(3)}{",pool" if m.group(4) == "true" else ""}>'
+        return f'conv<{m.group(1)}->{m.group(2)},s1{",pool" if m.group(3) == "true" else ""}>'
+    m = re.search(r'conv3x3_s2_mfma<(\d+), (\d+)', name)
+    if m:
+        return f'conv<{m.group(1)}->{m.group(2)},s2>'
     m = re.search(r'(\w+)(<|\()', name.replace('(anonymous namespace)::', '').replace('void ', ''))
     return m.group(1) if m else name[:40]
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))

@@ -4,9 +4,15 @@ usage: summarize.py <kernel_stats.csv> <pmc_fetch/counter_collection.csv> <pmc_w
 import csv, json, re, sys, collections
 
 def short(name):
-    m = re.search(r'conv3x3_mfma<(\d+), (\d+), (\d), (true|false)', name)
+    m = re.search(r'conv3x3_mfma<(\d+), (\d+), (true|false)', name)
     if m:
-        return f'conv3x3_mfma<{m.group(1)}->{m.group(2)},s{m.group(3)}{",pool" if m.group(4) == "true" else ""}>'
+        return f'conv3x3_mfma<{m.group(1)}->{m.group(2)},s1{",pool" if m.group(3) == "true" else ""}>'
+    m = re.search(r'conv3x3_s2_mfma<(\d+), (\d+)', name)
+    if m:
+        return f'conv3x3_s2_mfma<{m.group(1)}->{m.group(2)},s2>'
+    m = re.search(r'hungarian_pair_kernel<(\d)>', name)
+    if m:
+        return f'hungarian_pair_kernel<gap{m.group(1)}>'
     m = re.search(r'(\w+)(<|\()', name.replace('(anonymous namespace)::', '').replace('void ', ''))
     return m.group(1) if m else name[:60]
 
@@ -34,3 +40,12 @@ with open(f'profiles/{tag}_kernels.csv', 'w') as out:
         r['total_us'] = round(r['total_us'], 1); r['avg_us'] = round(r['avg_us'], 2)
         wr.writerow(r)
 print(open(f'profiles/{tag}_kernels.csv').read())
+# per-launch HBM traffic of the dominant kernel for bench.py's roofline.traffic (gfx950: FETCH_SIZE counts 64 B per
+# 128-B request for wide coalesced reads -> doubled per MI355X_MICROARCH.md; WRITE_SIZE is exact; units KB)
+dom = max((r for r in rows if r['kernel'].startswith('conv3x3')), key=lambda r: r['total_us'])
+traffic = {'kernel': dom['kernel'], 'fetch_kb_raw': dom['FETCH_SIZE_KB_per_launch'], 'write_kb': dom['WRITE_SIZE_KB_per_launch'],
+           'hbm_bytes_per_launch': int((2 * dom['FETCH_SIZE_KB_per_launch'] + dom['WRITE_SIZE_KB_per_launch']) * 1024),
+           'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py; FETCH doubled (gfx950 correction '
+                   'for wide coalesced reads; this kernel mixes 4-B and 16-B loads, so the doubled figure is an upper bound)'}
+json.dump(traffic, open(f'profiles/{tag}_traffic.json', 'w'), indent=1)
+print(traffic)
