@@ -71,7 +71,7 @@ __device__ __forceinline__ void load_bias(const float *__restrict__ bias, int gr
     }
 }
 
-template <int COUT, bool POOL, int MT, int NT>
+template <int COUT, bool POOL, int MT, int NT, bool BIAS_IN_ACC = false>
 __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[MT][NT], const float (&bias_v)[NT],
                                               float *__restrict__ out, int b, int grp, int y0, int x0, int wave, int p,
                                               int q, int Hout, int Wout)
@@ -80,7 +80,7 @@ __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[MT][NT], const 
     for (int n = 0; n < NT; ++n) {
         const int ch = grp * NT * 16 + n * 16 + p;
         if (ch >= COUT) continue;
-        const float bv = bias_v[n];
+        const float bv = BIAS_IN_ACC ? 0.f : bias_v[n];
         float *och = out + ((long)b * COUT + ch) * Hout * Wout;
         if constexpr (!POOL) {
 #pragma unroll
@@ -88,8 +88,8 @@ __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[MT][NT], const 
                 f32x4 v = acc[m][n];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float t = v[j] + bv;
-                    v[j] = t > 0.f ? t : t * 0.1f;
+                    const float t = BIAS_IN_ACC ? v[j] : v[j] + bv;
+                    v[j] = fmaxf(t, t * 0.1f);          // LeakyReLU(0.1): t > 0 ? t : 0.1 t
                 }
                 const int row = y0 + wave * MT + m, x = x0 + q * 4;
                 *reinterpret_cast<f32x4 *>(och + (long)row * Wout + x) = v;
@@ -254,37 +254,42 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(
 
 // ------------------------------------------------------------------------------------------------
 // stride-2 conv3x3 (conv blocks 0 and 1): low arithmetic intensity, so data movement decides the speed.
-//   * the 33-row input patch is staged as rows of 40 floats starting 3 columns left of the patch
-//     (2*x0 - 4, a multiple of 4): aligned 16-byte global loads and ds_write_b128 instead of scalars;
-//   * K is ordered k = c*9 + ky*3 + kx per chunk and addressed through a per-lane offset table, so the four
-//     k of one MFMA step mostly differ in kx: with stride-2 pixel addresses (even banks) the next k lands on
-//     the odd banks -- conflict-free without padding the planes;
-//   * ALL the layer's weights stay in LDS for the life of the (persistent) workgroup; only patches stream,
-//     software-pipelined across chunks and tiles as in conv3x3_mfma.
+//   * every WAVE is its own pipeline: it stages the 9 input rows its 4 output rows need (rows of 36 floats starting
+//     3 columns left of the patch, 2*x0 - 4, a multiple of 4: aligned 16-byte global loads and ds_write_b128) into a
+//     wave-private LDS region. The main loop therefore has no workgroup barrier; the waves of a CU drift apart and
+//     the loads, MFMAs and stores of different waves overlap. Halo rows shared by two waves are staged twice (9 rows
+//     instead of 8.25).
+//   * the next (tile, chunk)'s loads are issued into registers before the MFMAs of the current one and written to
+//     LDS after them; the zero mask for padding is applied at that store, so nothing touches the loaded registers
+//     (and forces a wait) while the MFMAs run. Workgroups are persistent and walk an XCD-contiguous tile list.
+//   * K is ordered k = c*9 + ky*3 + kx per chunk and addressed through a per-lane offset table, so the four k of one
+//     MFMA step mostly differ in kx: with stride-2 pixel addresses (even banks) the next k lands on the odd banks.
+//   * ALL the layer's weights stay in LDS for the life of the workgroup (staged once, one barrier).
 //   conv block 0 (FIRST) gathers its 5 channels straight from frames t..t+4 of the timelapse at the tile origin
 //   (fuses Timelapse.get_frametiles_stack, Timelapse.py:111-125,150-157), zero beyond the tile and the frame.
 // ------------------------------------------------------------------------------------------------
 template <int CIN, int COUT, int NPC, int NT, bool FIRST, int WPS>
 __global__ __launch_bounds__(256) void conv3x3_s2_mfma(
     const float *__restrict__ in, const float *__restrict__ wpk, const float *__restrict__ bias,
-    float *__restrict__ out, int Hin, int B,
+    float *__restrict__ out, const float *__restrict__ zeros, int Hin, int B,
     int Hf, int Wf, int t0, int tstep, int item0, int n_tiles, TileList tl)
 {
-    constexpr int MT = 4, PH = 33, RW = 40, PLANE = PH * RW;
+    constexpr int MT = 4, PHW = 9, RW = 36, PLANE = PHW * RW;        // per wave: 9 rows x 36 floats per channel
+    int rag_jx0 = 0, rag_limx = 0;                                    // only used for ragged (unaligned) frames
+    constexpr int WREGION = NPC * PLANE + 4;                          // + one spare float4 (dummy store target)
     constexpr int NCHUNK = CIN / NPC;
     constexpr int KREAL = 9 * NPC, KSTEPS = (KREAL + 3) / 4, KROWS = KSTEPS * 4;
     constexpr int NPADW = npadw(NT);
     static_assert(CIN % NPC == 0, "CIN must be a multiple of the chunk");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *patch = smem;                      // [NPC][33][40]
-    float *wl = smem + NPC * PLANE;           // [NCHUNK][KROWS][NPADW]  (whole layer)
-
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *patch = smem + wave * WREGION;     // this wave's [NPC][9][36]
+    float *wl = smem + 4 * WREGION;           // [NCHUNK][KROWS][NPADW]  (whole layer, shared)
+
     const int p = lane & 15, q = lane >> 4;
     const int tiles_x = Hin / 32, ntile = tiles_x * tiles_x;     // output is Hin/2, tiles of 16
     const WorkRange wr = my_work(ntile * B);
-    if (wr.begin >= wr.end) return;
 
     // the layer's weights: once per workgroup
     {
@@ -293,6 +298,8 @@ __global__ __launch_bounds__(256) void conv3x3_s2_mfma(
         f32x4 *l4 = reinterpret_cast<f32x4 *>(wl);
         for (int e = tid; e < NW4; e += 256) l4[e] = w4[e];
     }
+    __syncthreads();
+    if (wr.begin >= wr.end) return;
 
     int koff[KSTEPS];
 #pragma unroll
@@ -301,102 +308,92 @@ __global__ __launch_bounds__(256) void conv3x3_s2_mfma(
         const int kk = k < KREAL ? k : 0;                  // padded k rows carry zero weights
         koff[s] = (kk / 9) * PLANE + ((kk % 9) / 3) * RW + (kk % 3) + 3;
     }
-    const int a_base = (wave * MT * 2) * RW + 2 * p;
+    const int a_base = 2 * p;
     const int b_base = q * NPADW + p;
 
-    // staging plan (float4 granularity): element e = tid + k*256 is (channel c, row r, 4-column segment).
-    // Branch-free: segments past the patch go to a dummy LDS slot (an extra 16 bytes behind the weights), rows or
-    // segments outside the image load from a clamped address and are zeroed by selects.
-    constexpr int NP4 = NPC * PH * (RW / 4);
-    constexpr int NPE = (NP4 + 255) / 256;
-    constexpr int DUMMY = NPC * PLANE + NCHUNK * KROWS * NPADW;     // float offset of the spare float4
-    int loff[NPE];
+    // staging plan of the wave (float4 granularity): element e = lane + k*64 is (channel c, row r, 4-column segment).
+    // The decomposition is done once; per tile an element costs one add (its offset), a few compares and an
+    // address select: lanes whose segment lies outside the image read a 16-byte block of zeros instead, so zero
+    // padding needs no masking of the loaded data (nothing consumes the loaded registers before the MFMAs).
+    constexpr int NP4 = NPC * PHW * (RW / 4);
+    constexpr int NPE = (NP4 + 63) / 64;
+    constexpr int DUMMY = NPC * PLANE;                    // the wave's spare float4
+    int loff[NPE], crs[NPE];                 // LDS offset; packed (c << 16 | r << 8 | seg), c = 255 for "no element"
 #pragma unroll
     for (int k = 0; k < NPE; ++k) {
-        const int e = tid + k * 256;
-        const int c = e / (PH * (RW / 4)), rem = e - c * (PH * (RW / 4));
+        const int e = lane + k * 64;
+        const int c = e / (PHW * (RW / 4)), rem = e - c * (PHW * (RW / 4));
         const int r = rem / (RW / 4), seg = rem - r * (RW / 4);
         loff[k] = e < NP4 ? (c * PLANE + r * RW + 4 * seg) : DUMMY;
+        crs[k] = e < NP4 ? ((c << 16) | (r << 8) | seg) : (255 << 16);
     }
-    int goff[NPE];                           // global offset inside (item, chunk 0) of the segment's first float
-    int gx0[NPE];                            // its column, or a large negative number when the row is invalid
+    const float *pl[NPE];                    // this step's load addresses
     f32x4 pv[NPE];
 
     int cur_b = 0, cur_y0 = 0, cur_x0 = 0;
-    int nxt_b = 0, nxt_y0 = 0, nxt_x0 = 0, nxt_limx = 0, nxt_cstride = 0, nxt_aligned = 0;
-    long nxt_src = 0;
+    int nxt_b = 0, nxt_y0 = 0, nxt_x0 = 0, nxt_cstride = 0, nxt_aligned = 0;
     auto decode_plan = [&](int w) {
         const int tile = w % ntile;
         nxt_b = w / ntile;
         nxt_y0 = (tile / tiles_x) * 16;
         nxt_x0 = (tile % tiles_x) * 16;
-        int lim_y, rstride;
+        int lim_y, lim_x, rstride;
+        long src;
         if constexpr (FIRST) {
             const int item = item0 + nxt_b;
             const int t = t0 + (item / n_tiles) * tstep, k = item % n_tiles;
             const int oy = tl.yx[2 * k] * AXT_TILE, ox = tl.yx[2 * k + 1] * AXT_TILE;
-            nxt_src = ((long)t * Hf + oy) * Wf + ox;
+            src = ((long)t * Hf + oy) * Wf + ox;
             nxt_cstride = Hf * Wf;
             rstride = Wf;
             lim_y = min(AXT_TILE, Hf - oy);
-            nxt_limx = min(AXT_TILE, Wf - ox);
-            nxt_aligned = (Wf % 4 == 0) && (nxt_limx % 4 == 0);
+            lim_x = min(AXT_TILE, Wf - ox);
+            nxt_aligned = (Wf % 4 == 0) && (lim_x % 4 == 0);
         } else {
-            nxt_src = (long)nxt_b * CIN * Hin * Hin;
+            src = (long)nxt_b * CIN * Hin * Hin;
             nxt_cstride = Hin * Hin;
             rstride = Hin;
             lim_y = Hin;
-            nxt_limx = Hin;
+            lim_x = Hin;
             nxt_aligned = 1;
         }
-        const int iy0 = nxt_y0 * 2 - 1, jx0 = nxt_x0 * 2 - 4;     // first staged row / column (a multiple of 4)
+        // first staged row of this wave / first staged column (a multiple of 4)
+        const int iy0 = (nxt_y0 + wave * MT) * 2 - 1, jx0 = nxt_x0 * 2 - 4;
+        const float *base = in + src + (long)iy0 * rstride + jx0;
 #pragma unroll
         for (int k = 0; k < NPE; ++k) {
-            const int e = tid + k * 256;
-            const int c = e / (PH * (RW / 4)), rem = e - c * (PH * (RW / 4));
-            const int r = rem / (RW / 4), seg = rem - r * (RW / 4);
+            const int c = crs[k] >> 16, r = (crs[k] >> 8) & 255, seg = crs[k] & 255;
             const int gy = iy0 + r, gx = jx0 + 4 * seg;
-            const bool rowok = e < NP4 && gy >= 0 && gy < lim_y;
-            goff[k] = c * nxt_cstride + gy * rstride + gx;
-            gx0[k] = rowok ? gx : -(1 << 20);
+            // aligned images: a segment is entirely inside or entirely outside. Ragged ones (width not a multiple
+            // of 4) take the per-float path in load_chunk and only need the row test here.
+            const bool ok = c < NPC && gy >= 0 && gy < lim_y && (!nxt_aligned || (gx >= 0 && gx + 3 < lim_x));
+            pl[k] = ok ? base + (c * nxt_cstride + r * rstride + 4 * seg) : zeros;
         }
+        if (!nxt_aligned) { rag_jx0 = jx0; rag_limx = lim_x; }
     };
-    auto load_chunk = [&](int chunk) {       // loads (nxt item or current item: the plan in goff/gx0), chunk
-        const float *csrc = in + nxt_src + (long)chunk * NPC * nxt_cstride;
-        // raw loads from clamped addresses; the zero mask is applied in store_chunk, so that nothing consumes
-        // the loaded registers (and forces a wait) before the MFMAs of the current step have been issued
+    auto load_chunk = [&](int chunk) {
+        const long coff = (long)chunk * NPC * nxt_cstride;
         if (nxt_aligned) {
 #pragma unroll
-            for (int k = 0; k < NPE; ++k) {
-                const bool ok = gx0[k] >= 0 && gx0[k] + 3 < nxt_limx;
-                pv[k] = *reinterpret_cast<const f32x4 *>(csrc + (ok ? goff[k] : 0));
-            }
+            for (int k = 0; k < NPE; ++k)
+                pv[k] = *reinterpret_cast<const f32x4 *>(pl[k] == zeros ? zeros : pl[k] + coff);
         } else {
 #pragma unroll
             for (int k = 0; k < NPE; ++k) {
+                const int gx = rag_jx0 + 4 * (crs[k] & 255);
                 f32x4 v;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const bool ok = gx0[k] + j >= 0 && gx0[k] + j < nxt_limx;
-                    v[j] = csrc[ok ? goff[k] + j : 0];
+                    const bool ok = pl[k] != zeros && gx + j >= 0 && gx + j < rag_limx;
+                    v[j] = ok ? pl[k][coff + j] : 0.f;
                 }
                 pv[k] = v;
             }
         }
     };
-    auto store_chunk = [&]() {          // masks refer to the plan the registers were loaded with (still current)
+    auto store_chunk = [&]() {
 #pragma unroll
-        for (int k = 0; k < NPE; ++k) {
-            f32x4 v = pv[k];
-            if (nxt_aligned) {
-                if (!(gx0[k] >= 0 && gx0[k] + 3 < nxt_limx)) v = f32x4{0.f, 0.f, 0.f, 0.f};
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (!(gx0[k] + j >= 0 && gx0[k] + j < nxt_limx)) v[j] = 0.f;
-            }
-            *reinterpret_cast<f32x4 *>(patch + loff[k]) = v;
-        }
+        for (int k = 0; k < NPE; ++k) *reinterpret_cast<f32x4 *>(patch + loff[k]) = pv[k];
     };
     float bias_v[NT];
     load_bias<COUT, NT>(bias, 0, p, bias_v);
@@ -411,14 +408,11 @@ __global__ __launch_bounds__(256) void conv3x3_s2_mfma(
     decode_plan(w);
     cur_b = nxt_b; cur_y0 = nxt_y0; cur_x0 = nxt_x0;
     load_chunk(0);
-    bool first = true;
     const int Hout = Hin / 2;
 #pragma unroll 1
     for (;;) {
-        if (!first) __syncthreads();
-        first = false;
+        // LDS accesses of one wave execute in order: the reads of the previous step are done before these writes
         store_chunk();
-        __syncthreads();                      // also covers the one-time weight staging
         const bool last_chunk = (chunk == NCHUNK - 1);
         const bool has_next = w + wr.step < wr.end;
         if (!last_chunk) {
@@ -562,6 +556,7 @@ struct axt_detector {
     float *d_bfc[3] = {};
     float *d_act[8] = {};       // activations after conv block i (chunk-sized for i < 4)
     float *d_slab = nullptr, *d_fc1 = nullptr, *d_fc2 = nullptr;
+    float *d_zeros = nullptr;   // 64 bytes of zeros: the address out-of-image lanes load from
     size_t bytes = 0;
     // optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg)
     bool profiling = false;
@@ -681,13 +676,13 @@ int launch_conv(const float *in, const float *w, const float *bias, float *out, 
 }
 
 template <int CIN, int COUT, int NPC, int NT, bool FIRST, int WPS>
-int launch_conv_s2(const float *in, const float *w, const float *bias, float *out, int Hin, int B, hipStream_t st,
-                   int Hf = 0, int Wf = 0, int t0 = 0, int tstep = 1, int item0 = 0, int n_tiles = 1,
+int launch_conv_s2(const float *in, const float *w, const float *bias, float *out, const float *zeros, int Hin, int B,
+                   hipStream_t st, int Hf = 0, int Wf = 0, int t0 = 0, int tstep = 1, int item0 = 0, int n_tiles = 1,
                    const TileList *tl = nullptr)
 {
     auto kern = conv3x3_s2_mfma<CIN, COUT, NPC, NT, FIRST, WPS>;
     constexpr int KROWS = ((9 * NPC + 3) / 4) * 4;
-    constexpr size_t lds = (size_t)(NPC * 33 * 40 + (CIN / NPC) * KROWS * npadw(NT) + 4) * sizeof(float);
+    constexpr size_t lds = (size_t)(4 * (NPC * 9 * 36 + 4) + (CIN / NPC) * KROWS * npadw(NT)) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         AXT_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -703,7 +698,7 @@ int launch_conv_s2(const float *in, const float *w, const float *bias, float *ou
         AXT_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)kern, 256, lds));
         per_cu = n < 1 ? 1 : (n > 8 ? 8 : n);
     }
-    hipLaunchKernelGGL(kern, dim3(persistent_grid(nwork, per_cu)), dim3(256), lds, st, in, w, bias, out, Hin, B, Hf, Wf,
+    hipLaunchKernelGGL(kern, dim3(persistent_grid(nwork, per_cu)), dim3(256), lds, st, in, w, bias, out, zeros, Hin, B, Hf, Wf,
                        t0, tstep, item0, n_tiles, tl ? *tl : dummy);
     AXT_LAUNCH_CHECK();
     return AXT_OK;
@@ -736,12 +731,12 @@ int run_front_a(axt_detector *d, const float *frames, int Hf, int Wf, int t0, in
     int rc;
     {
         ProfSpan ps(d, st, 0, nb);
-        if ((rc = launch_conv_s2<5, 20, 5, 2, true, 4>(frames, d->d_wconv[0], d->d_bconv[0], d->d_act[0], 512, nb, st, Hf, Wf,
+        if ((rc = launch_conv_s2<5, 20, 5, 2, true, 4>(frames, d->d_wconv[0], d->d_bconv[0], d->d_act[0], d->d_zeros, 512, nb, st, Hf, Wf,
                                                     t0, tstep, item0, n_tiles, &tl))) return rc;
     }
     {
         ProfSpan ps(d, st, 1, nb);
-        if ((rc = launch_conv_s2<20, 40, 5, 3, false, 3>(d->d_act[0], d->d_wconv[1], d->d_bconv[1], d->d_act[1], 256, nb,
+        if ((rc = launch_conv_s2<20, 40, 5, 3, false, 3>(d->d_act[0], d->d_wconv[1], d->d_bconv[1], d->d_act[1], d->d_zeros, 256, nb,
                                                       st))) return rc;
     }
     {
@@ -897,6 +892,11 @@ int axt_detector_create(const float *const *h_tensors, int n_tensors, int max_ba
     if (!rc) rc = dev_alloc(d, &d->d_slab, (size_t)kFc1Split * max_batch * kFc);
     if (!rc) rc = dev_alloc(d, &d->d_fc1, (size_t)max_batch * kFc);
     if (!rc) rc = dev_alloc(d, &d->d_fc2, (size_t)max_batch * kFc);
+    if (!rc) rc = dev_alloc(d, &d->d_zeros, (size_t)16);
+    if (!rc && hipMemset(d->d_zeros, 0, 64) != hipSuccess) {
+        axt_set_error("hipMemset failed");
+        rc = AXT_EHIP;
+    }
     if (!rc && hipDeviceSynchronize() != hipSuccess) {
         axt_set_error("device synchronize failed after upload");
         rc = AXT_EHIP;
@@ -924,6 +924,7 @@ void axt_detector_destroy(axt_detector *d)
     (void)hipFree(d->d_slab);
     (void)hipFree(d->d_fc1);
     (void)hipFree(d->d_fc2);
+    (void)hipFree(d->d_zeros);
     for (auto &sp : d->spans) {
         (void)hipEventDestroy(sp.a);
         (void)hipEventDestroy(sp.b);
