@@ -25,6 +25,8 @@ SIGNATURES = {
     'axt_detector_set_profiling': (c_int, [c_void_p, c_int]),
     'axt_detector_read_profile': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     'axt_cnn_kernel_flops_per_tile': (c_double, [c_int]),
+    'axt_preprocess_u16': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_int, c_float, c_void_p,
+                                   c_void_p]),
     'axt_tile_occupancy': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'axt_decode_stitch_nms': (c_int, [c_void_p, c_int, c_int, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_void_p]),

@@ -125,6 +125,22 @@ class Detector:
         return out
 
 
+def preprocess_u16(raw, mask=None, offset=0.0, clip_lower=0.0, log_correct=True, scale=1.0):
+    """Fused dense preprocessing (Timelapse.py:205-326) of a raw uint16 timelapse that already sits on the GPU.
+    raw: torch.uint16 (or int16-viewed) [T,H,W]; mask: uint8/bool [H,W] on the same device or None."""
+    T, H, W = raw.shape
+    assert raw.is_contiguous() and raw.element_size() == 2
+    out = torch.empty((T, H, W), dtype=torch.float32, device=raw.device)
+    if mask is not None:
+        mask = mask.to(device=raw.device, dtype=torch.uint8).contiguous()
+    lib = _lib.load()
+    with torch.cuda.device(raw.device):
+        _lib.check(lib.axt_preprocess_u16(raw.data_ptr(), _lib.dptr(mask), T, H, W, ctypes.c_float(offset),
+                                          ctypes.c_float(clip_lower), int(bool(log_correct)), ctypes.c_float(scale),
+                                          out.data_ptr(), _stream()), 'axt_preprocess_u16')
+    return out
+
+
 def tile_occupancy(frames):
     """Kept tiles, row-major list of (tile_row, tile_col) (Timelapse.py:551-558)."""
     T_all, H, W = frames.shape

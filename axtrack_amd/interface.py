@@ -76,7 +76,7 @@ def prepare_input_data(imseq_fname, parameters, dest_dir, inference_data_dir, st
         mask = np.asarray(mask_fname)
     frames = preprocess(imseq, mask, offset=input_metadata.get('intensity_offset'),
                         clip=input_metadata.get('clip_intensity'), log_correct=parameters.get('LOG_CORRECT', True),
-                        scale=stnd_scaler[1][0])
+                        scale=stnd_scaler[1][0], device=parameters['DEVICE'])
     return Timelapse(frames, name=name, mask=mask, temporal_context=parameters['TEMPORAL_CONTEXT'],
                      tilesize=parameters['TILESIZE'], device=parameters['DEVICE'],
                      pixelsize=input_metadata.get('pixelsize'), dt=input_metadata.get('dt_min'),

@@ -45,26 +45,19 @@ class Timelapse:
         return self.frames.device
 
 
-def preprocess(imseq, mask=None, offset=121, clip=55, log_correct=True, scale=0.015176106):
+def preprocess(imseq, mask=None, offset=121, clip=55, log_correct=True, scale=0.015176106, device='cuda:0'):
     """Dense preprocessing of a raw uint16 timelapse as Timelapse._read_tiff / _clip_image_values /
-    _log_adjust_image / _standardize do it (Timelapse.py:205-326): u16 -> f32 in [0,1], mask,
-    subtract offset/2^16 and clamp at 0, zero below clip/2^16, log2(1+x), divide by the train-set
-    std. `img_as_float32` and `adjust_log` are skimage functions that are absent here: their
-    arithmetic (x/65535, log2(1+x)) is restated from the published skimage 0.18 behaviour,
-    PARITY UNPINNED (a "next" row)."""
-    x = torch.as_tensor(np.asarray(imseq))
-    if x.dtype in (torch.uint16, torch.int32, torch.int16):
-        x = x.to(torch.float32) / 65535.0
-    else:
-        x = x.to(torch.float32)
-    if mask is not None:
-        x = x * torch.as_tensor(np.asarray(mask)).to(torch.float32)
-    if offset:
-        off = offset / 2 ** 16 if isinstance(offset, int) else offset
-        x = (x - off).clamp_(min=0)
-    if clip:
-        lo = clip / 2 ** 16 if isinstance(clip, int) else clip
-        x = torch.where(x < lo, torch.zeros_like(x), x)
-    if log_correct:
-        x = torch.log2(1 + x)
-    return x / scale
+    _log_adjust_image / _standardize do it (Timelapse.py:205-326), as one fused HIP pass
+    (axt_preprocess_u16): u16 -> f32 in [0,1], mask, subtract offset/2^16 and clamp at 0, zero below
+    clip/2^16, log2(1+x), divide by the train-set std. `img_as_float32` and `adjust_log` are skimage
+    functions that are absent here: their arithmetic (x * (1/65535), log2(1+x)) is restated from the
+    published skimage 0.18 behaviour, PARITY UNPINNED (a "next" row)."""
+    from . import hotpath as hp
+    a = np.asarray(imseq)
+    if a.dtype != np.uint16:
+        raise TypeError(f'raw timelapses are uint16 (got {a.dtype}); pass preprocessed float32 frames to Timelapse directly')
+    raw = torch.from_numpy(np.ascontiguousarray(a).view(np.int16)).to(device)
+    off = 0.0 if not offset else (offset / 2 ** 16 if isinstance(offset, int) else float(offset))
+    lo = 0.0 if not clip else (clip / 2 ** 16 if isinstance(clip, int) else float(clip))
+    m = None if mask is None else torch.from_numpy(np.ascontiguousarray(np.asarray(mask).astype(np.uint8)))
+    return hp.preprocess_u16(raw, m, off, lo, bool(log_correct), float(scale))

@@ -92,6 +92,16 @@ int axt_detector_read_profile(axt_detector *det, double *ms, int64_t *launches, 
 double axt_cnn_kernel_flops_per_tile(int kernel);
 
 /* ------------------------------------------------------------------------------------------
+ * Preprocessing ("next" row of the scope table, in front of the hot path): the dense part of
+ * Timelapse._read_tiff, _clip_image_values, _log_adjust_image, _standardize
+ * (Timelapse.py:205-326) as one fused pass: x = u16/65535 -> mask -> max(x-offset,0) ->
+ * (x<clip_lower ? 0 : x) -> log2(1+x) -> x/scale. d_raw u16 [T,H,W]; d_mask u8 [H,W] or NULL;
+ * offset / clip_lower in [0,1] units (0 = skip); d_out f32 [T,H,W].
+ * ------------------------------------------------------------------------------------------ */
+int axt_preprocess_u16(const uint16_t *d_raw, const uint8_t *d_mask, int T, int H, int W, float offset,
+                       float clip_lower, int log_correct, float scale, float *d_out, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Tiling: which 512x512 tiles the reference keeps (Timelapse.py:551-558): a tile is kept if
  * any pixel of it is > 0 at any t. d_occ u8 [ceil(H/512)*ceil(W/512)] row-major, 1 = keep.
  * ------------------------------------------------------------------------------------------ */

@@ -84,6 +84,24 @@ def cnn_forward(sd, X, n_threads=None):
     return x.reshape(B, 12, 12, 3)
 
 
+# ------------------------------------------------------------------------------- f-1 (next row)
+def preprocess(raw_u16, mask=None, offset=0.0, clip_lower=0.0, log_correct=True, scale=1.0):
+    """Dense part of Timelapse._read_tiff/_clip_image_values/_log_adjust_image/_standardize
+    (Timelapse.py:205-326) in numpy f32. img_as_float32 (x * (1/65535)) and adjust_log (log2(1+x)) are
+    skimage functions absent here, restated from their published behaviour: PARITY UNPINNED."""
+    x = np.multiply(raw_u16, 1. / 65535, dtype=np.float32)
+    if mask is not None:
+        x[:, ~np.asarray(mask, bool)] = 0
+    if offset:
+        x -= np.float32(offset)
+        x[x < 0] = 0
+    if clip_lower:
+        x[x < np.float32(clip_lower)] = 0
+    if log_correct:
+        x = np.log2(1 + x / np.float32(1.0)) * np.float32(1.0)
+    return (x / np.float32(scale)).astype(np.float32)
+
+
 # ------------------------------------------------------------------------------- a-2 / tiling
 def tile_grid(H, W, ts=512):
     return int(np.ceil(H / ts)), int(np.ceil(W / ts))

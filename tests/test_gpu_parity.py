@@ -416,3 +416,39 @@ def test_two_rank_frame_sharding(weights):
         ad = _run_inference(frames, weights, P, name='shard')
         ref = (ad.n_ids, ad._track_flat.tobytes(), ad.IDed_dets_all.to_numpy().tobytes())
         assert res[0][mode] == ref and res[1][mode] == ref, mode
+
+
+# ----------------------------------------------------------------------------------------- f-1 (next row)
+def test_preprocess_fused_pass_matches_oracle():
+    rng = np.random.default_rng(3)
+    T, H, W = 5, 300, 420                                   # W*H not a multiple of 8 per row, odd total tail
+    raw = rng.integers(0, 5000, (T, H, W)).astype(np.uint16)
+    raw[rng.uniform(size=raw.shape) < 0.7] = 0
+    mask = synth.corridor_mask(H, W, 40, 128)
+    from axtrack_amd.timelapse import preprocess
+    got = preprocess(raw, mask, offset=121, clip=55, log_correct=True, scale=0.015176106).cpu().numpy()
+    ref = orc.preprocess(raw, mask, 121 / 2 ** 16, 55 / 2 ** 16, True, 0.015176106)
+    assert np.array_equal(got == 0, ref == 0)               # same sparsity pattern (mask, offset clamp, clip)
+    np.testing.assert_array_max_ulp(got, ref, maxulp=2)     # log2f: GPU and numpy are each within 1 ulp
+    got2 = preprocess(raw[:, :, :416].copy(), None, offset=0, clip=0, log_correct=False, scale=1.0).cpu().numpy()
+    assert np.array_equal(got2, orc.preprocess(raw[:, :, :416], None, 0, 0, False, 1.0))
+
+
+def test_example_script_runs_the_three_step_api(tmp_path):
+    """examples/test.py: setup_inference -> prepare_input_data (raw uint16) -> inference -> IDed_dets_all, with the
+    'to' caches written in the reference's file layout and readable with 'from'."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location('example_test', os.path.join(os.path.dirname(__file__), '..', 'examples', 'test.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ad = mod.main(T=12, dest_dir=str(tmp_path))
+    df = ad.IDed_dets_all
+    assert df.shape[1] == 3 * 8 and df.index.name == 'axonID' and len(df) == ad.n_ids >= 1
+    assert os.path.exists(tmp_path / 'axon_dets' / 'example_timelapse__detections.pkl')
+    assert os.path.exists(tmp_path / 'axon_dets' / 'example_timelapse__IDed_detections.pkl')
+    # the caches round-trip
+    import axtrack_amd
+    ad2 = axtrack_amd.AxonDetections(ad.model, ad.dataset, ad.P, ad.dir)
+    ad2.detect_dataset(cache='from')
+    ad2.assign_ids(assigedIDs_cache='from')
+    assert np.array_equal(np.nan_to_num(ad2.IDed_dets_all.to_numpy(), nan=-1), np.nan_to_num(df.to_numpy(), nan=-1))
