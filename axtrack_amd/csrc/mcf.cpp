@@ -165,13 +165,15 @@ struct Lsap {
     std::vector<int32_t> touched_cols, sr_rows;
     std::vector<std::pair<int64_t, int32_t>> heap;   // binary min-heap of (key, column), storage reused
     size_t stat_rows = 0, stat_cols = 0;
+    size_t *hist = nullptr, *histn = nullptr;
 
     void insert_row(int i)
     {
         typedef std::pair<int64_t, int32_t> Item;
         heap.clear();
         int64_t minVal = 0;
-        int cur = i, sink = -1;
+        int64_t best_free = INF;          // shortest distance to a FREE column seen so far: nothing at or beyond it
+        int cur = i, sink = -1;           // can be part of the shortest augmenting path, so it is not even queued
         sr_rows.clear();
         while (sink < 0) {
             sr_rows.push_back(cur);
@@ -179,6 +181,8 @@ struct Lsap {
             auto relax = [&](int j, int64_t c, int32_t arc) {
                 if (in_sc[j]) return;
                 const int64_t r = minVal + c - ucur - v[j];
+                if (r >= best_free) return;
+                if (row4col[j] < 0) best_free = r;
                 if (r < spc[j]) {
                     if (spc[j] == INF) touched_cols.push_back(j);
                     spc[j] = r;
@@ -228,6 +232,7 @@ struct Lsap {
         }
         stat_rows += sr_rows.size();
         stat_cols += touched_cols.size();
+        if (hist) { size_t b = 0, x = sr_rows.size(); while (x > 1) { x >>= 1; ++b; } hist[b < 15 ? b : 15] += sr_rows.size(); histn[b < 15 ? b : 15]++; }
         for (int32_t c : touched_cols) { spc[c] = INF; in_sc[c] = 0; }
         touched_cols.clear();
     }
@@ -243,7 +248,10 @@ struct Lsap {
         pred_row.assign(2 * (size_t)n, -1);
         pred_arc.assign(2 * (size_t)n, -1);
         in_sc.assign(2 * (size_t)n, 0);
+        size_t h1[16] = {0}, h2[16] = {0};
+        if (getenv("AXT_MCF_DEBUG")) { hist = h1; histn = h2; }
         for (int i = 0; i < n; ++i) insert_row(i);
+        if (hist) for (int b = 0; b < 16; ++b) fprintf(stderr, "  insertions scanning [%d,%d) rows: %zu insertions, %zu rows\n", 1 << b, 2 << b, h2[b], h1[b]);
         if (getenv("AXT_MCF_DEBUG"))
             fprintf(stderr, "lsap: n=%d rows scanned=%zu cols touched=%zu\n", n, stat_rows, stat_cols);
     }
