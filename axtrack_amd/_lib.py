@@ -30,6 +30,8 @@ SIGNATURES = {
     'axt_tile_occupancy': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'axt_decode_stitch_nms': (c_int, [c_void_p, c_int, c_int, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_void_p]),
+    'axt_grid_create': (c_int, [c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    'axt_grid_destroy': (None, [c_void_p]),
     'axt_obs_costs': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p]),
     'axt_path_cost': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                               c_int, c_void_p, c_void_p]),

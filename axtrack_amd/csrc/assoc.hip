@@ -15,6 +15,11 @@
 int axt_path_cost_masked(const int32_t *d_xa, const int32_t *d_ya, int na, const int32_t *d_xb, const int32_t *d_yb,
                          int nb, const uint8_t *d_mask, int H, int W, int max_dist, int conn8, int32_t *d_D,
                          hipStream_t st);
+struct axt_grid;
+extern "C" const uint8_t *axt_grid_mask(const axt_grid *g);
+int axt_masked_distance_table(const axt_grid *g, const int32_t *d_x, const int32_t *d_y, const int32_t *d_count,
+                              int n_frames, int cap, int max_dist, int max_gap, const int32_t *h_dmax,
+                              const int32_t *d_dmax, int16_t *d_Dtmp, hipStream_t st);
 
 namespace {
 
@@ -106,15 +111,16 @@ __global__ void frame_offsets_kernel(const int *__restrict__ count, int n_frames
 }
 
 // One wave per (source detection a of frame t, gap g): scans the detections of frame t+g, 64 per step.
+// TABLE: path lengths come from the masked-grid BFS pass instead of the closed form.
 // FILL == false: writes the number of admitted targets to cnt[(a_global)*max_gap + g-1].
 // FILL == true : writes the arcs at row_ptr[a_global] + (arcs of smaller gaps) in ascending b.
-template <bool FILL>
+template <bool FILL, bool TABLE>
 __global__ __launch_bounds__(256) void arcs_open_kernel(
     const int *__restrict__ x, const int *__restrict__ y, const int *__restrict__ count,
     const int *__restrict__ frame_off, int n_frames, int cap, int H, int W, int max_dist, int conn8, int max_gap,
     const int *__restrict__ dmax, int *__restrict__ cnt, const long *__restrict__ row_ptr,
     int *__restrict__ col, short *__restrict__ len, unsigned char *__restrict__ gapv,
-    const long *__restrict__ cost_units, long *__restrict__ cost)
+    const long *__restrict__ cost_units, long *__restrict__ cost, const short *__restrict__ Dtmp)
 {
     const int t = blockIdx.x;
     const int na = min(count[t], cap);
@@ -137,7 +143,14 @@ __global__ __launch_bounds__(256) void arcs_open_kernel(
             for (int j0 = 0; j0 < nb; j0 += 64) {
                 const int j = j0 + lane;
                 int d = max_dist;
-                if (j < nb) d = path_len_open(xa, ya, x[(long)tb * cap + j], y[(long)tb * cap + j], H, W, max_dist, conn8);
+                if (j < nb) {
+                    if (TABLE) {        // masked grid: path lengths were computed by the BFS pass (0 = no arc)
+                        d = Dtmp[(((long)t * cap + i) * max_gap + (g - 1)) * cap + j];
+                        if (d <= 0) d = max_dist;
+                    } else {
+                        d = path_len_open(xa, ya, x[(long)tb * cap + j], y[(long)tb * cap + j], H, W, max_dist, conn8);
+                    }
+                }
                 const bool ok = (j < nb) && (d <= lim);
                 const unsigned long long m = __ballot(ok);
                 if (FILL && ok) {
@@ -215,13 +228,13 @@ int axt_obs_costs(const float *d_conf, const int32_t *d_count, int n_frames, int
 }
 
 int axt_path_cost(const int32_t *d_xa, const int32_t *d_ya, int na, const int32_t *d_xb, const int32_t *d_yb, int nb,
-                  const uint8_t *d_mask, int H, int W, int max_dist, int conn8, int32_t *d_D, void *stream)
+                  const axt_grid *grid, int H, int W, int max_dist, int conn8, int32_t *d_D, void *stream)
 {
     AXT_REQUIRE(na >= 0 && nb >= 0 && H > 0 && W > 0 && max_dist > 0 && max_dist < 32768, "bad argument");
     if ((long)na * nb == 0) return AXT_OK;
     AXT_REQUIRE(d_xa && d_ya && d_xb && d_yb && d_D, "null argument");
     hipStream_t st = (hipStream_t)stream;
-    if (d_mask) return axt_path_cost_masked(d_xa, d_ya, na, d_xb, d_yb, nb, d_mask, H, W, max_dist, conn8, d_D, st);
+    if (grid) return axt_path_cost_masked(d_xa, d_ya, na, d_xb, d_yb, nb, axt_grid_mask(grid), H, W, max_dist, conn8, d_D, st);
     const long n = (long)na * nb;
     hipLaunchKernelGGL(path_cost_open_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_xa, d_ya, na, d_xb,
                        d_yb, nb, H, W, max_dist, conn8, d_D);
@@ -230,26 +243,38 @@ int axt_path_cost(const int32_t *d_xa, const int32_t *d_ya, int na, const int32_
 }
 
 int axt_build_arcs(const int32_t *d_x, const int32_t *d_y, const int32_t *d_count, int n_frames, int cap,
-                   const uint8_t *d_mask, int H, int W, int max_dist, int conn8, int max_gap, const int32_t *h_dmax,
+                   const axt_grid *grid, int H, int W, int max_dist, int conn8, int max_gap, const int32_t *h_dmax,
                    int64_t *d_row_ptr, int32_t *d_work, int32_t *d_col, int16_t *d_len, uint8_t *d_gap,
                    const int64_t *d_cost_units, int64_t *d_cost, int64_t *n_arcs, void *stream)
 {
     AXT_REQUIRE(d_x && d_y && d_count && h_dmax && d_row_ptr && d_work && n_arcs, "null argument");
     AXT_REQUIRE(n_frames >= 1 && cap >= 1 && max_gap >= 1 && max_gap <= 8, "bad argument");
-    AXT_REQUIRE(d_mask == nullptr, "axt_build_arcs: masked grids go through axt_path_cost (see DESIGN.md)");
     hipStream_t st = (hipStream_t)stream;
-    // d_work layout: cnt [n_frames*cap*max_gap] | frame_off [n_frames+1] | dmax [max_gap]
+    // d_work layout: cnt [n_frames*cap*max_gap] | frame_off [n_frames+1] | dmax [max_gap] | pad |
+    //                masked grids only: Dtmp i16 [n_frames*cap*max_gap*cap]
     int *cnt = d_work;
     int *frame_off = d_work + (size_t)n_frames * cap * max_gap;
     int *dmax = frame_off + n_frames + 1;
-    const dim3 grid(n_frames, 8), block(256);
+    short *Dtmp = reinterpret_cast<short *>(d_work + (((size_t)n_frames * cap * max_gap + n_frames + 1 + max_gap + 3) & ~(size_t)3));
+    const dim3 grid_dim(n_frames, 8), block(256);
     if (d_col == nullptr) {
         AXT_CHECK_HIP(hipMemcpyAsync(dmax, h_dmax, sizeof(int) * max_gap, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(frame_offsets_kernel, dim3(1), dim3(1024), 0, st, d_count, n_frames, cap, frame_off);
         AXT_LAUNCH_CHECK();
-        hipLaunchKernelGGL(arcs_open_kernel<false>, grid, block, 0, st, d_x, d_y, d_count, frame_off, n_frames, cap, H,
-                           W, max_dist, conn8, max_gap, dmax, cnt, (const long *)nullptr, (int *)nullptr,
-                           (short *)nullptr, (unsigned char *)nullptr, (const long *)nullptr, (long *)nullptr);
+        if (grid) {
+            const int rc = axt_masked_distance_table(grid, d_x, d_y, d_count, n_frames, cap, max_dist, max_gap, h_dmax, dmax,
+                                                     Dtmp, st);
+            if (rc) return rc;
+            hipLaunchKernelGGL((arcs_open_kernel<false, true>), grid_dim, block, 0, st, d_x, d_y, d_count, frame_off, n_frames,
+                               cap, H, W, max_dist, conn8, max_gap, dmax, cnt, (const long *)nullptr, (int *)nullptr,
+                               (short *)nullptr, (unsigned char *)nullptr, (const long *)nullptr, (long *)nullptr,
+                               (const short *)Dtmp);
+        } else {
+            hipLaunchKernelGGL((arcs_open_kernel<false, false>), grid_dim, block, 0, st, d_x, d_y, d_count, frame_off, n_frames,
+                               cap, H, W, max_dist, conn8, max_gap, dmax, cnt, (const long *)nullptr, (int *)nullptr,
+                               (short *)nullptr, (unsigned char *)nullptr, (const long *)nullptr, (long *)nullptr,
+                               (const short *)nullptr);
+        }
         AXT_LAUNCH_CHECK();
         hipLaunchKernelGGL(row_ptr_kernel, dim3(1), dim3(1024), 0, st, cnt, frame_off, n_frames, max_gap,
                            (long *)d_row_ptr);
@@ -265,9 +290,14 @@ int axt_build_arcs(const int32_t *d_x, const int32_t *d_y, const int32_t *d_coun
     }
     AXT_REQUIRE(d_len && d_gap, "null argument");
     AXT_REQUIRE((d_cost == nullptr) == (d_cost_units == nullptr), "d_cost and d_cost_units go together");
-    hipLaunchKernelGGL(arcs_open_kernel<true>, grid, block, 0, st, d_x, d_y, d_count, frame_off, n_frames, cap, H, W,
-                       max_dist, conn8, max_gap, dmax, cnt, (const long *)d_row_ptr, d_col, d_len, d_gap,
-                       (const long *)d_cost_units, (long *)d_cost);
+    if (grid)
+        hipLaunchKernelGGL((arcs_open_kernel<true, true>), grid_dim, block, 0, st, d_x, d_y, d_count, frame_off, n_frames, cap, H,
+                           W, max_dist, conn8, max_gap, dmax, cnt, (const long *)d_row_ptr, d_col, d_len, d_gap,
+                           (const long *)d_cost_units, (long *)d_cost, (const short *)Dtmp);
+    else
+        hipLaunchKernelGGL((arcs_open_kernel<true, false>), grid_dim, block, 0, st, d_x, d_y, d_count, frame_off, n_frames, cap,
+                           H, W, max_dist, conn8, max_gap, dmax, cnt, (const long *)d_row_ptr, d_col, d_len, d_gap,
+                           (const long *)d_cost_units, (long *)d_cost, (const short *)nullptr);
     AXT_LAUNCH_CHECK();
     return AXT_OK;
 }

@@ -4,8 +4,8 @@
 // For one source detection the lengths to ALL targets come from a single-source search, instead of one A* per
 // (source, target) pair as the reference does (AxonDetections.py:570-576): one workgroup per source.
 //
-// Definition (identical to the CPU checker's): inside the window of half-width max_dist around the source,
-// find the minimum-cost 4-/8-connected path to each target, cost of a move = weight of the cell moved into.
+// Definition (identical to the CPU checker's): on the whole grid, find the minimum-cost 4-/8-connected path to
+// each target, cost of a move = weight of the cell moved into.
 // With weights {1, 65536} and fewer than 65536 on-mask moves the cost order equals the lexicographic order of
 // (off-mask cells entered, moves), packed here as the 64-bit key off << 32 | moves (moves can exceed 16 bits in
 // a 1001^2 window). The result is moves + 1 cells, or max_dist ("None")
@@ -17,6 +17,12 @@
 // shortest-path key of every cell, independent of scheduling. First correct version: the frontiers live in HBM
 // and each step costs two workgroup barriers (a bit-parallel LDS variant is the planned optimisation).
 #include "axt_common.h"
+
+#include <new>
+#include <vector>
+
+struct axt_grid;
+extern "C" void axt_grid_destroy(axt_grid *g);
 
 namespace {
 
@@ -43,8 +49,7 @@ __global__ __launch_bounds__(256) void path_sssp_kernel(
         for (int j = tid; j < nb; j += 256) Drow[j] = max_dist;
         return;
     }
-    const int y0 = max(sy - max_dist, 0), y1 = min(sy + max_dist, H - 1);
-    const int x0 = max(sx - max_dist, 0), x1 = min(sx + max_dist, W - 1);
+    const int y0 = 0, y1 = H - 1, x0 = 0, x1 = W - 1;      // the search runs on the whole grid
     const int wh = y1 - y0 + 1, ww = x1 - x0 + 1;
     const long ncell = (long)wh * ww;
     u64 *key = sc.key + (long)src * win_cells_cap;
@@ -113,7 +118,7 @@ int axt_path_cost_masked(const int32_t *d_xa, const int32_t *d_ya, int na, const
                          int nb, const uint8_t *d_mask, int H, int W, int max_dist, int conn8, int32_t *d_D,
                          hipStream_t st)
 {
-    const long win = (long)(2 * max_dist + 1 < H ? 2 * max_dist + 1 : H) * (2 * max_dist + 1 < W ? 2 * max_dist + 1 : W);
+    const long win = (long)H * W;
     // sources are processed in batches so that the HBM scratch (24 bytes per window cell and source) stays bounded
     const long bytes_per_src = win * (8 + 4 + 4 + 4);
     long batch = (long)(8ll << 30) / bytes_per_src;     // <= 8 GiB of scratch
@@ -133,5 +138,321 @@ int axt_path_cost_masked(const int32_t *d_xa, const int32_t *d_ya, int na, const
         AXT_LAUNCH_CHECK();
     }
     AXT_CHECK_HIP(hipFreeAsync(raw, st));
+    return AXT_OK;
+}
+
+// =====================================================================================================================
+// Fast path for the arc builder on a masked grid.
+//
+// Only path lengths up to dmax (251 cells at gap 1, 86 at gap 2) can become arcs. For a target T that is reachable
+// from the source S through on-mask cells only, the minimum-cost path IS the shortest on-mask path (every off-mask
+// cell costs 65536), so its length is a plain breadth-first distance -- and whether such a path exists at all is a
+// property of the mask's connected components, computed once per timelapse (axt_grid_create). Hence per source:
+//   * level-0 targets (T == S, or T on the mask in a component S touches): BFS over on-mask cells, depth-limited to
+//     dmax-1 moves; not reached within that depth => the optimum is longer than dmax cells => no arc;
+//   * other targets (off-mask, or in a component S does not touch) close enough that a path of <= dmax cells could
+//     exist: marked for the exact general search above (rare in real data: detections sit on the mask).
+// The BFS is bit-parallel: the (2R+1)^2 window around S lives in LDS as three bitmaps (reached A/B, mask M); one BFS
+// step is a 4-/8-neighbour dilation of whole 32-cell words, AND-ed with the mask. One workgroup per source serves
+// the targets of BOTH following frames (gaps 1 and 2).
+// =====================================================================================================================
+struct axt_grid {
+    int H = 0, W = 0, Ww = 0, conn8 = 0;
+    unsigned char *d_mask = nullptr;     // [H][W] 0/1
+    unsigned int *d_bits = nullptr;      // [H][Ww] bit x%32 of word x/32, zero-padded
+    int *d_label = nullptr;              // [H][W] connected-component label >= 1 on the mask, 0 off it
+};
+
+namespace {
+
+constexpr int BFS_R = 250;                       // moves; cells <= 251
+constexpr int BFS_WH = 2 * BFS_R + 1;            // window rows
+constexpr int BFS_WW = 18;                       // window words per row: 501 bits + up to 31 bits of alignment + guard
+
+__device__ __forceinline__ unsigned int dil_h(const unsigned int *row, int w)
+{
+    const unsigned int c = row[w];
+    const unsigned int l = w > 0 ? row[w - 1] : 0u, r = w + 1 < BFS_WW ? row[w + 1] : 0u;
+    return c | (c << 1) | (l >> 31) | (c >> 1) | (r << 31);
+}
+
+// Dtmp[((t*cap + i) * max_gap + g-1) * cap + j]: path length (cells) if <= dmax[g-1], 0 = no arc, -1 = needs exact search
+constexpr int BFS_THREADS = 1024;      // one workgroup per CU (LDS-bound): many waves hide the LDS latency of the sweeps
+
+__global__ __launch_bounds__(BFS_THREADS) void mask_bfs_kernel(
+    const int *__restrict__ x, const int *__restrict__ y, const int *__restrict__ count, int n_frames, int cap,
+    const unsigned int *__restrict__ bits, const int *__restrict__ label, int H, int W, int Ww, int conn8,
+    int max_dist, int max_gap, const int *__restrict__ dmax, short *__restrict__ Dtmp)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned int bsm[];
+    unsigned int *A = bsm, *Bm = A + BFS_WH * BFS_WW, *M = Bm + BFS_WH * BFS_WW;
+    int *tpos = reinterpret_cast<int *>(M + BFS_WH * BFS_WW);      // [max_gap*cap] window bit position or -1
+    short *tres = reinterpret_cast<short *>(tpos + max_gap * cap); // [max_gap*cap]
+    __shared__ int s_labels[8];
+    __shared__ int n_slab, n_open;
+
+    const int t = blockIdx.y, i = blockIdx.x, tid = threadIdx.x;
+    if (i >= min(count[t], cap)) return;
+    const int sx = x[(long)t * cap + i], sy = y[(long)t * cap + i];
+    short *drow = Dtmp + ((long)t * cap + i) * max_gap * cap;
+    const bool s_in = sx >= 0 && sx < W && sy >= 0 && sy < H;
+    const int wy0 = sy - BFS_R, wx0 = ((sx - BFS_R) >> 5) << 5;     // window origin; columns word-aligned (floor)
+    int depth = 0;
+    for (int g = 0; g < max_gap; ++g) depth = max(depth, dmax[g] - 1);
+    depth = min(depth, BFS_R);
+
+    // ---- source labels
+    if (tid == 0) {
+        int n = 0;
+        if (s_in) {
+            const int ls = label[(long)sy * W + sx];
+            if (ls) s_labels[n++] = ls;
+            else {
+                const int nn = conn8 ? 8 : 4;
+                const int dy8[8] = {-1, 1, 0, 0, -1, -1, 1, 1}, dx8[8] = {0, 0, -1, 1, -1, 1, -1, 1};
+                for (int d = 0; d < nn; ++d) {
+                    const int ny = sy + dy8[d], nx = sx + dx8[d];
+                    if (ny < 0 || ny >= H || nx < 0 || nx >= W) continue;
+                    const int l = label[(long)ny * W + nx];
+                    bool seen = l == 0;
+                    for (int k = 0; k < n; ++k) seen |= s_labels[k] == l;
+                    if (!seen) s_labels[n++] = l;
+                }
+            }
+        }
+        n_slab = n;
+        n_open = 0;
+    }
+    // ---- window bitmaps
+    for (int e = tid; e < BFS_WH * BFS_WW; e += BFS_THREADS) {
+        const int r = e / BFS_WW, w = e - r * BFS_WW;
+        const int gy = wy0 + r, gw = (wx0 >> 5) + w;
+        M[e] = (gy >= 0 && gy < H && gw >= 0 && gw < Ww) ? bits[(long)gy * Ww + gw] : 0u;
+        A[e] = 0u;
+        Bm[e] = 0u;
+    }
+    __syncthreads();
+    // ---- targets of frames t+1 .. t+max_gap
+    for (int e = tid; e < max_gap * cap; e += BFS_THREADS) {
+        const int g = e / cap, j = e - g * cap, tb = t + g + 1;
+        int pos = -1;
+        short res = 0;
+        if (tb < n_frames && j < min(count[tb], cap) && s_in) {
+            const int tx = x[(long)tb * cap + j], ty = y[(long)tb * cap + j];
+            const long dx = tx - sx, dy = ty - sy;
+            const bool t_in = tx >= 0 && tx < W && ty >= 0 && ty < H;
+            const int lim = dmax[g];
+            const int lower = (conn8 ? (int)max(labs(dx), labs(dy)) : (int)(labs(dx) + labs(dy))) + 1;   // cells needed at least
+            if (t_in && dx * dx + dy * dy < (long)max_dist * max_dist && lower <= lim) {
+                if (dx == 0 && dy == 0) res = 1;
+                else {
+                    const int lt = label[(long)ty * W + tx];
+                    bool level0 = false;
+                    for (int k = 0; k < n_slab; ++k) level0 |= (lt != 0 && s_labels[k] == lt);
+                    if (level0) { pos = (ty - wy0) * (BFS_WW * 32) + (tx - wx0); atomicAdd(&n_open, 1); }
+                    else res = -1;                                    // exact search decides
+                }
+            }
+        }
+        tpos[e] = pos;
+        tres[e] = res;
+    }
+    if (tid == 0 && s_in) {
+        const int e = (sy - wy0) * BFS_WW + ((sx - wx0) >> 5);
+        A[e] |= 1u << ((sx - wx0) & 31);
+        M[e] |= 1u << ((sx - wx0) & 31);                              // the seed counts even off the mask
+    }
+    __syncthreads();
+
+    // ---- breadth-first search, one dilation per move
+    unsigned int *cur = A, *nxt = Bm;
+    const int sr = BFS_R, sc = sx - wx0;                              // the source's window row / column
+    for (int s = 1; s <= depth && n_open > 0; ++s) {
+        // after s moves only the cells within s of the source can be set: rows sr-s..sr+s, words of columns sc-s..sc+s
+        const int rlo = max(0, sr - s), rhi = min(BFS_WH - 1, sr + s);
+        const int wlo = max(0, (sc - s) >> 5), whi = min(BFS_WW - 1, (sc + s) >> 5), nw = whi - wlo + 1;
+        int changed = 0;
+        const float inv_nw = 1.0f / (float)nw;             // e < 9018, nw <= 18: (e + 0.5) * inv_nw truncates to e / nw exactly
+        for (int e = tid; e < (rhi - rlo + 1) * nw; e += BFS_THREADS) {
+            const int rr = (int)(((float)e + 0.5f) * inv_nw);
+            const int r = rlo + rr, w = wlo + (e - rr * nw);
+            const unsigned int *row = cur + r * BFS_WW;
+            unsigned int v;
+            if (conn8) {
+                v = dil_h(row, w);
+                if (r > 0) v |= dil_h(row - BFS_WW, w);
+                if (r + 1 < BFS_WH) v |= dil_h(row + BFS_WW, w);
+            } else {
+                v = dil_h(row, w);
+                if (r > 0) v |= row[w - BFS_WW];
+                if (r + 1 < BFS_WH) v |= row[w + BFS_WW];
+            }
+            v &= M[r * BFS_WW + w];
+            nxt[r * BFS_WW + w] = v;
+            changed |= (v != row[w]);
+        }
+        const int any = __syncthreads_or(changed);
+        for (int e = tid; e < max_gap * cap; e += BFS_THREADS) {
+            const int pos = tpos[e];
+            if (pos < 0) continue;
+            const int r = pos / (BFS_WW * 32), c = pos - r * (BFS_WW * 32);
+            if (nxt[r * BFS_WW + (c >> 5)] >> (c & 31) & 1u) {
+                tres[e] = (short)(s + 1);
+                tpos[e] = -1;
+                atomicSub(&n_open, 1);
+            }
+        }
+        __syncthreads();
+        unsigned int *sw = cur; cur = nxt; nxt = sw;
+        if (!any) break;
+    }
+    __syncthreads();
+    for (int e = tid; e < max_gap * cap; e += BFS_THREADS) {
+        const int g = e / cap;
+        short r = tres[e];
+        if (r > 0 && r > dmax[g]) r = 0;
+        drow[e] = r;
+    }
+}
+
+// per source: does any target need the exact search?
+__global__ void mask_flag_kernel(const short *__restrict__ Dtmp, const int *__restrict__ count, int n_frames, int cap,
+                                 int max_gap, int *__restrict__ flags, int *__restrict__ n_flagged)
+{
+    const int t = blockIdx.y, i = blockIdx.x;
+    if (i >= min(count[t], cap)) { if (threadIdx.x == 0) flags[(long)t * cap + i] = 0; return; }
+    const short *drow = Dtmp + ((long)t * cap + i) * max_gap * cap;
+    int any = 0;
+    for (int e = threadIdx.x; e < max_gap * cap; e += blockDim.x) any |= (drow[e] < 0);
+    any = __syncthreads_or(any);
+    if (threadIdx.x == 0) {
+        flags[(long)t * cap + i] = any;
+        if (any) atomicAdd(n_flagged, 1);
+    }
+}
+
+// after the exact search of one source against one frame: replace the -1 marks
+__global__ void mask_patch_kernel(short *__restrict__ drow, const int *__restrict__ Dexact, int nb, int lim)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nb) return;
+    if (drow[j] < 0) drow[j] = (Dexact[j] <= lim) ? (short)Dexact[j] : (short)0;
+}
+
+}  // namespace
+
+extern "C" int axt_grid_create(const uint8_t *h_mask, int H, int W, int conn8, axt_grid **out)
+{
+    AXT_REQUIRE(h_mask && out && H > 0 && W > 0, "bad argument");
+    axt_grid *g = new (std::nothrow) axt_grid();
+    if (!g) return AXT_ENOMEM;
+    g->H = H; g->W = W; g->Ww = (W + 31) / 32; g->conn8 = conn8 ? 1 : 0;
+    std::vector<unsigned int> bits((size_t)H * g->Ww, 0u);
+    std::vector<int> label((size_t)H * W, 0);
+    std::vector<unsigned char> m01((size_t)H * W);
+    for (long k = 0; k < (long)H * W; ++k) m01[k] = h_mask[k] == 1;          // AxonDetections.py:598: mask == 1
+    for (int yy = 0; yy < H; ++yy)
+        for (int xx = 0; xx < W; ++xx)
+            if (m01[(size_t)yy * W + xx]) bits[(size_t)yy * g->Ww + (xx >> 5)] |= 1u << (xx & 31);
+    // connected components by flood fill
+    std::vector<int> stack;
+    int next = 0;
+    const int nn = conn8 ? 8 : 4;
+    const int dy8[8] = {-1, 1, 0, 0, -1, -1, 1, 1}, dx8[8] = {0, 0, -1, 1, -1, 1, -1, 1};
+    for (long k = 0; k < (long)H * W; ++k) {
+        if (!m01[k] || label[k]) continue;
+        label[k] = ++next;
+        stack.push_back((int)k);
+        while (!stack.empty()) {
+            const int c = stack.back();
+            stack.pop_back();
+            const int cy = c / W, cx = c % W;
+            for (int d = 0; d < nn; ++d) {
+                const int ny = cy + dy8[d], nx = cx + dx8[d];
+                if (ny < 0 || ny >= H || nx < 0 || nx >= W) continue;
+                const int n = ny * W + nx;
+                if (m01[n] && !label[n]) { label[n] = next; stack.push_back(n); }
+            }
+        }
+    }
+    int rc = AXT_OK;
+    if (hipMalloc((void **)&g->d_mask, (size_t)H * W) != hipSuccess || hipMalloc((void **)&g->d_bits, bits.size() * 4) != hipSuccess ||
+        hipMalloc((void **)&g->d_label, label.size() * 4) != hipSuccess) {
+        axt_set_error("axt_grid_create: device allocation failed");
+        rc = AXT_ENOMEM;
+    } else if (hipMemcpy(g->d_mask, m01.data(), m01.size(), hipMemcpyHostToDevice) != hipSuccess ||
+               hipMemcpy(g->d_bits, bits.data(), bits.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+               hipMemcpy(g->d_label, label.data(), label.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        axt_set_error("axt_grid_create: upload failed");
+        rc = AXT_EHIP;
+    }
+    if (rc) { axt_grid_destroy(g); return rc; }
+    *out = g;
+    return AXT_OK;
+}
+
+extern "C" void axt_grid_destroy(axt_grid *g)
+{
+    if (!g) return;
+    (void)hipFree(g->d_mask);
+    (void)hipFree(g->d_bits);
+    (void)hipFree(g->d_label);
+    delete g;
+}
+
+extern "C" const uint8_t *axt_grid_mask(const axt_grid *g) { return g ? g->d_mask : nullptr; }
+
+// Fills Dtmp (layout above) for every source detection; exact-search fallback included. Synchronises the stream.
+int axt_masked_distance_table(const axt_grid *g, const int32_t *d_x, const int32_t *d_y, const int32_t *d_count,
+                              int n_frames, int cap, int max_dist, int max_gap, const int32_t *h_dmax,
+                              const int32_t *d_dmax, int16_t *d_Dtmp, hipStream_t st)
+{
+    for (int k = 0; k < max_gap; ++k)
+        AXT_REQUIRE(h_dmax[k] - 1 <= BFS_R, "masked arcs: dmax %d exceeds the BFS window (%d cells)", h_dmax[k], BFS_R + 1);
+    const size_t lds = (size_t)3 * BFS_WH * BFS_WW * 4 + (size_t)max_gap * cap * 6 + 16;
+    AXT_REQUIRE(lds <= 159 * 1024, "masked arcs: cap %d needs %zu bytes of LDS", cap, lds);
+    static bool attr = false;
+    if (!attr) {
+        AXT_CHECK_HIP(hipFuncSetAttribute((const void *)mask_bfs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL(mask_bfs_kernel, dim3(cap, n_frames), dim3(BFS_THREADS), lds, st, d_x, d_y, d_count, n_frames, cap, g->d_bits,
+                       g->d_label, g->H, g->W, g->Ww, g->conn8, max_dist, max_gap, d_dmax, d_Dtmp);
+    AXT_LAUNCH_CHECK();
+    int *flags = nullptr, *n_flagged = nullptr;
+    AXT_CHECK_HIP(hipMallocAsync((void **)&flags, sizeof(int) * ((size_t)n_frames * cap + 1), st));
+    n_flagged = flags + (size_t)n_frames * cap;
+    AXT_CHECK_HIP(hipMemsetAsync(n_flagged, 0, sizeof(int), st));
+    hipLaunchKernelGGL(mask_flag_kernel, dim3(cap, n_frames), dim3(64), 0, st, d_Dtmp, d_count, n_frames, cap, max_gap, flags,
+                       n_flagged);
+    AXT_LAUNCH_CHECK();
+    int nf = 0;
+    AXT_CHECK_HIP(hipMemcpyAsync(&nf, n_flagged, sizeof(int), hipMemcpyDeviceToHost, st));
+    AXT_CHECK_HIP(hipStreamSynchronize(st));
+    if (nf > 0) {
+        std::vector<int> hf((size_t)n_frames * cap), hc(n_frames);
+        AXT_CHECK_HIP(hipMemcpy(hf.data(), flags, hf.size() * 4, hipMemcpyDeviceToHost));
+        AXT_CHECK_HIP(hipMemcpy(hc.data(), d_count, (size_t)n_frames * 4, hipMemcpyDeviceToHost));
+        int *dex = nullptr;
+        AXT_CHECK_HIP(hipMalloc((void **)&dex, sizeof(int) * cap));
+        for (int t = 0; t < n_frames; ++t)
+            for (int i = 0; i < hc[t] && i < cap; ++i) {
+                if (!hf[(size_t)t * cap + i]) continue;
+                for (int gp = 0; gp < max_gap; ++gp) {
+                    const int tb = t + gp + 1;
+                    if (tb >= n_frames) continue;
+                    const int nb = hc[tb] < cap ? hc[tb] : cap;
+                    if (nb == 0) continue;
+                    int rc = axt_path_cost_masked(d_x + (size_t)t * cap + i, d_y + (size_t)t * cap + i, 1, d_x + (size_t)tb * cap,
+                                                  d_y + (size_t)tb * cap, nb, g->d_mask, g->H, g->W, max_dist, g->conn8, dex, st);
+                    if (rc) { (void)hipFree(dex); return rc; }
+                    hipLaunchKernelGGL(mask_patch_kernel, dim3((nb + 255) / 256), dim3(256), 0, st,
+                                       d_Dtmp + (((size_t)t * cap + i) * max_gap + gp) * cap, (const int *)dex, nb, h_dmax[gp]);
+                }
+            }
+        AXT_CHECK_HIP(hipStreamSynchronize(st));
+        (void)hipFree(dex);
+    }
+    AXT_CHECK_HIP(hipFreeAsync(flags, st));
     return AXT_OK;
 }

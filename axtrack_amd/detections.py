@@ -254,12 +254,13 @@ class AxonDetections(object):
         return out
 
     def _mask_dev(self):
+        """The timelapse's mask as a device grid handle (bit rows + connected components), built once."""
         m = self.dataset.mask2d
         if m is None:
             return None
-        if getattr(self, '_mask_t', None) is None:
-            self._mask_t = torch.from_numpy(np.ascontiguousarray(m, np.uint8)).to(self.device)
-        return self._mask_t
+        if getattr(self.dataset, '_grid', None) is None or self.dataset._grid.conn8 != self.conn8:
+            self.dataset._grid = hp.Grid(m, self.conn8, self.device)
+        return self.dataset._grid
 
     def _assign_IDs_to_detections(self):
         """AxonDetections.py:631-715 with the tracker replaced by axt_build_arcs + axt_mcf_solve
@@ -287,12 +288,9 @@ class AxonDetections(object):
         if mode != 'mcf':
             raise ValueError(f"parameters['ASSOCIATION'] must be 'mcf' or 'hungarian', got {mode!r}")
         obs = hp.obs_costs(self.d_conf, self.d_count, P['MCF_CONF_CAPPING_METHOD'], P['MCF_MAX_CONF_COST'])
-        if masked:
-            row_ptr, col, cost = self._masked_arcs(dmax, units)
-        else:
-            row_ptr, col, length, gap, cost = hp.build_arcs(self.d_x, self.d_y, self.d_count, self.dataset.sizey,
-                                                            self.dataset.sizex, dmax, units, None,
-                                                            self.max_px_assoc_dist, self.conn8)
+        row_ptr, col, length, gap, cost = hp.build_arcs(self.d_x, self.d_y, self.d_count, self.dataset.sizey,
+                                                        self.dataset.sizex, dmax, units, self._mask_dev(),
+                                                        self.max_px_assoc_dist, self.conn8)
         cnt, conf, x, y = self._host_dets()
         offs = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
         n_det = int(offs[-1])
@@ -315,41 +313,6 @@ class AxonDetections(object):
         self.mcf_total_cost, self.n_ids = total, n_tracks
         self._track_flat, self._offs = track, offs
         return True
-
-    def _masked_arcs(self, dmax, units):
-        """Admissible arcs on a masked grid: one single-source path search per detection and frame pair
-        (axt_path_cost with the mask), thresholded and packed into the CSR layout of axt_build_arcs
-        (rows by tail detection, sorted by (gap, head)). Correct but not yet fused into one kernel."""
-        cnt = self._host_dets()[0]
-        offs = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
-        n_det = int(offs[-1])
-        mask = self._mask_dev()
-        dev = self.device
-        units_d = torch.as_tensor(units).to(dev)
-        tails, heads, gaps, costs = [], [], [], []
-        for t in range(len(cnt)):
-            for g in range(1, len(dmax) + 1):
-                tb = t + g
-                if tb >= len(cnt) or cnt[t] == 0 or cnt[tb] == 0:
-                    continue
-                na, nb = int(cnt[t]), int(cnt[tb])
-                D = hp.path_cost(self.d_x[t, :na], self.d_y[t, :na], self.d_x[tb, :nb], self.d_y[tb, :nb],
-                                 self.dataset.sizey, self.dataset.sizex, mask, self.max_px_assoc_dist, self.conn8)
-                ij = torch.nonzero(D <= int(dmax[g - 1]))
-                if ij.numel() == 0:
-                    continue
-                a = ij[:, 0] + int(offs[t]); b = ij[:, 1] + int(offs[tb])
-                tails.append(a); heads.append(b); gaps.append(torch.full_like(a, g))
-                costs.append(_arc_cost_int_torch(units_d[g - 1][D[ij[:, 0], ij[:, 1]].long()], 3, a, b))
-        if not tails:
-            return torch.zeros(n_det + 1, dtype=torch.int64, device=dev), torch.zeros(0, dtype=torch.int32, device=dev), \
-                torch.zeros(0, dtype=torch.int64, device=dev)
-        a, b, g, c = torch.cat(tails), torch.cat(heads), torch.cat(gaps), torch.cat(costs)
-        order = torch.argsort((a * 16 + g) * (n_det + 1) + b)
-        a, b, c = a[order], b[order], c[order]
-        row_ptr = torch.zeros(n_det + 1, dtype=torch.int64, device=dev)
-        row_ptr[1:] = torch.cumsum(torch.bincount(a, minlength=n_det), 0)
-        return row_ptr, b.to(torch.int32), c
 
     def ided_arrays(self):
         """(frame i32, id i32, conf f32, x i32, y i32) of every IDed detection, frame-major."""

@@ -188,15 +188,37 @@ def obs_costs(conf, count, method='scale_to_max', max_conf_cost=4.6):
     return cost
 
 
+class Grid:
+    """Masked grid handle (axt_grid): byte mask, bit rows and connected-component labels on the GPU."""
+
+    def __init__(self, mask, conn8=False, device='cuda:0'):
+        _require_gpu()
+        m = np.ascontiguousarray(np.asarray(mask) == 1, np.uint8)
+        self.H, self.W, self.conn8 = int(m.shape[0]), int(m.shape[1]), bool(conn8)
+        self._lib = _lib.load()
+        h = ctypes.c_void_p()
+        with torch.cuda.device(torch.device(device)):
+            _lib.check(self._lib.axt_grid_create(m.ctypes.data, self.H, self.W, int(self.conn8), ctypes.byref(h)),
+                       'axt_grid_create')
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h:
+            self._lib.axt_grid_destroy(h)
+
+
 def path_cost(xa, ya, xb, yb, H, W, mask=None, max_dist=MAX_PX_ASSOC_DIST, conn8=False):
     """A* path-length matrix of one frame pair (AxonDetections.py:526-629,717-752)."""
     na, nb = xa.numel(), xb.numel()
     D = torch.empty((na, nb), dtype=torch.int32, device=xa.device)
     lib = _lib.load()
+    if mask is not None and not isinstance(mask, Grid):
+        mask = Grid(mask.cpu().numpy() if isinstance(mask, torch.Tensor) else mask, conn8, xa.device)
     with torch.cuda.device(xa.device):
         _lib.check(lib.axt_path_cost(xa.data_ptr(), ya.data_ptr(), na, xb.data_ptr(), yb.data_ptr(), nb,
-                                     _lib.dptr(mask), H, W, int(max_dist), int(bool(conn8)), D.data_ptr(),
-                                     _stream()), 'axt_path_cost')
+                                     mask._h if mask is not None else None, H, W, int(max_dist), int(bool(conn8)),
+                                     D.data_ptr(), _stream()), 'axt_path_cost')
     return D
 
 
@@ -209,10 +231,15 @@ def build_arcs(x, y, count, H, W, dmax, cost_units=None, mask=None, max_dist=MAX
     dev = x.device
     h_dmax = np.ascontiguousarray(dmax, np.int32)
     row_ptr = torch.empty((n_frames * cap + 1,), dtype=torch.int64, device=dev)
-    work = torch.empty((n_frames * cap * max_gap + n_frames + 1 + max_gap,), dtype=torch.int32, device=dev)
+    n_work = n_frames * cap * max_gap + n_frames + 1 + max_gap + 4
+    if mask is not None:
+        if not isinstance(mask, Grid):
+            mask = Grid(mask.cpu().numpy() if isinstance(mask, torch.Tensor) else mask, conn8, dev)
+        n_work += (n_frames * cap * max_gap * cap + 1) // 2
+    work = torch.empty((n_work,), dtype=torch.int32, device=dev)
     n_arcs = ctypes.c_int64(0)
     lib = _lib.load()
-    args = (x.data_ptr(), y.data_ptr(), count.data_ptr(), n_frames, cap, _lib.dptr(mask), H, W, int(max_dist),
+    args = (x.data_ptr(), y.data_ptr(), count.data_ptr(), n_frames, cap, mask._h if mask is not None else None, H, W, int(max_dist),
             int(bool(conn8)), max_gap, h_dmax.ctypes.data, row_ptr.data_ptr(), work.data_ptr())
     with torch.cuda.device(dev):
         _lib.check(lib.axt_build_arcs(*args, None, None, None, None, None, ctypes.byref(n_arcs), _stream()),

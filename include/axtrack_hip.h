@@ -129,16 +129,24 @@ int axt_decode_stitch_nms(const float *d_yolo, int n_frames, int n_tiles, const 
 int axt_obs_costs(const float *d_conf, const int32_t *d_count, int n_frames, int cap,
                   int method, double max_conf_cost, double *d_cost, void *stream);
 
+/* A masked grid: the reference's weight image {1 on mask, 65536 off} (AxonDetections.py:587-598) in the forms the
+ * kernels need -- byte mask, bit-packed rows and connected-component labels (4- or 8-connected, flood fill on the
+ * host). Built once per timelapse from a HOST mask u8 [H,W] (1 = on mask). Synchronous. */
+typedef struct axt_grid axt_grid;
+int axt_grid_create(const uint8_t *h_mask, int H, int W, int conn8, axt_grid **out);
+void axt_grid_destroy(axt_grid *grid);
+
 /* _compute_detections_astar_paths + _get_astar_path_distances for ONE frame pair
  * (AxonDetections.py:526-629,717-752; A* call utils.py:379): D[i,j] = number of cells on the
  * minimum-cost 4-connected (conn8: 8-connected) path from detection i of the earlier frame
  * (rows) to detection j of the later frame on weights {1 on mask, 65536 off}; max_dist where
  * the euclidean distance is >= max_dist, an end point is outside the grid, or the path has
- * more than max_dist cells. d_mask u8 [H,W] (1 = on mask) or NULL for an all-ones mask
- * (closed form). D i32 [na, nb] row-major. */
+ * more than max_dist cells. grid = NULL for an all-ones mask (closed form); with a grid its
+ * connectivity must equal conn8 (exact single-source search per detection of the earlier frame).
+ * D i32 [na, nb] row-major. */
 int axt_path_cost(const int32_t *d_xa, const int32_t *d_ya, int na,
                   const int32_t *d_xb, const int32_t *d_yb, int nb,
-                  const uint8_t *d_mask, int H, int W, int max_dist, int conn8,
+                  const axt_grid *grid, int H, int W, int max_dist, int conn8,
                   int32_t *d_D, void *stream);
 
 /* All admissible transition arcs of a timelapse in one pass (what transition_model,
@@ -147,16 +155,20 @@ int axt_path_cost(const int32_t *d_xa, const int32_t *d_ya, int na,
  * Detections are numbered globally in frame order (frame offsets = prefix sum of counts).
  * CSR by tail: d_row_ptr i64 [n_det+1] (allocate n_frames*cap+1); d_col i32 [n_arcs] (global
  * index of b), d_len i16 [n_arcs] (D), d_gap u8 [n_arcs]. Rows are sorted by (gap, b):
- * deterministic. d_work i32 [n_frames*cap*max_gap + n_frames + 1 + max_gap] is scratch that
+ * deterministic. d_work i32 [n_frames*cap*max_gap + n_frames + 1 + max_gap + 4] (plus, with a masked grid,
+ * n_frames*cap*max_gap*cap/2 for the i16 path-length table) is scratch that
  * must stay untouched between the two phases:
  *   phase 1: d_col == NULL -> counts, row_ptr, *n_arcs (synchronises the stream);
  *   phase 2: d_col/d_len/d_gap sized by *n_arcs -> filled (asynchronous).
  * Optional integer arc costs: d_cost_units i64 [max_gap, max_dist+1] holds round(cost*1e6) of
  * transition_model for every (gap, D); d_cost i64 [n_arcs] then receives
  * axt_arc_cost_int-compatible values (units << 16 | hash16(3, a, b)). Both NULL to skip.
- * d_mask must be NULL (all-ones mask) in this version; masked grids use axt_path_cost. */
+ * grid = NULL: all-ones mask, closed-form path lengths. With a grid, path lengths come from one bit-parallel
+ * breadth-first search per detection over the on-mask cells (depth h_dmax-1 <= 250 moves; connected components
+ * decide which targets that search can reach) and, for the rare targets only reachable across off-mask cells,
+ * from the exact search of axt_path_cost. */
 int axt_build_arcs(const int32_t *d_x, const int32_t *d_y, const int32_t *d_count, int n_frames, int cap,
-                   const uint8_t *d_mask, int H, int W, int max_dist, int conn8,
+                   const axt_grid *grid, int H, int W, int max_dist, int conn8,
                    int max_gap, const int32_t *h_dmax,
                    int64_t *d_row_ptr, int32_t *d_work, int32_t *d_col, int16_t *d_len, uint8_t *d_gap,
                    const int64_t *d_cost_units, int64_t *d_cost, int64_t *n_arcs, void *stream);

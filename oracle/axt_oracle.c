@@ -109,8 +109,8 @@ void orc_linear(const float *x, int B, int In, const float *w, const float *bias
  * algorithm: A* on the pixel grid, cost of a move = weight of the cell moved INTO,
  * 4-connected by default (conn8 != 0: 8-connected, diagonal moves cost the same), optimal
  * because the L1 / Chebyshev heuristic times min(weights) >= 1 is admissible. Returns the
- * number of cells on a minimum-cost path, or 0 ("None") when that path has more than
- * max_len cells. For weights in {1, 65536} (AxonDetections.py:598) every minimum-cost
+ * number of cells on a minimum-cost path over the whole grid, or 0 ("None") when that path
+ * has more than max_len cells. For weights in {1, 65536} (AxonDetections.py:598) every minimum-cost
  * path has the same cell count, so the result does not depend on tie-breaking; we
  * therefore run Dijkstra on (cost, cells) which is exact and simple.
  * ------------------------------------------------------------------------------------ */
@@ -148,9 +148,8 @@ int orc_astar_len(const float *weights, int H, int W, int sy, int sx, int ty, in
                   int max_len, int conn8)
 {
     if (sy < 0 || sy >= H || sx < 0 || sx >= W || ty < 0 || ty >= H || tx < 0 || tx >= W) return 0;
-    /* search window: a minimum-cost path of <= max_len cells stays inside it */
-    const int y0 = (sy - max_len < 0) ? 0 : sy - max_len, y1 = (sy + max_len >= H) ? H - 1 : sy + max_len;
-    const int x0 = (sx - max_len < 0) ? 0 : sx - max_len, x1 = (sx + max_len >= W) ? W - 1 : sx + max_len;
+    /* the search runs on the whole grid, like upstream pyastar2d */
+    const int y0 = 0, y1 = H - 1, x0 = 0, x1 = W - 1;
     const int wh = y1 - y0 + 1, ww = x1 - x0 + 1;
     double *cost = (double *)malloc(sizeof(double) * wh * ww);
     int32_t *cells = (int32_t *)malloc(sizeof(int32_t) * wh * ww);

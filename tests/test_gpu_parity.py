@@ -452,3 +452,63 @@ def test_example_script_runs_the_three_step_api(tmp_path):
     ad2.detect_dataset(cache='from')
     ad2.assign_ids(assigedIDs_cache='from')
     assert np.array_equal(np.nan_to_num(ad2.IDed_dets_all.to_numpy(), nan=-1), np.nan_to_num(df.to_numpy(), nan=-1))
+
+
+@pytest.mark.parametrize('conn8', [False, True])
+def test_build_arcs_masked_grid_matches_oracle(conn8):
+    """The bit-parallel on-mask BFS + connected components + exact fallback must give exactly the arcs the oracle's
+    per-pair searches give: corridor mask with a gap and a disconnected island, detections on and off the mask."""
+    from axtrack_amd.detections import transition_cost_table
+    H, W = 300, 420
+    mask = synth.corridor_mask(H, W, width=24, pitch=80)
+    mask[100:140, :] = False
+    mask[110:130, 200:260] = True                               # an island: on the mask but in its own component
+    rng = np.random.default_rng(11 + conn8)
+    F, cap = 5, 40
+    ys, xs = np.nonzero(mask)
+    dets = []
+    for t in range(F):
+        n = int(rng.integers(18, 30))
+        k = rng.choice(len(ys), n, replace=False)
+        px, py = xs[k].copy(), ys[k].copy()
+        off = rng.uniform(size=n) < 0.25                          # a quarter of them anywhere, mostly off the mask
+        px[off] = rng.integers(0, W, off.sum()); py[off] = rng.integers(0, H, off.sum())
+        if t == 2:
+            px[0], py[0] = 230, 120                               # on the island
+            px[1], py[1] = -4, 50                                 # outside the grid
+        conf = np.sort(rng.uniform(0.55, 1.1, n).astype(np.float32))[::-1]
+        dets.append((conf, px.astype(np.int64), py.astype(np.int64)))
+    x = np.zeros((F, cap), np.int32); y = np.zeros((F, cap), np.int32)
+    for t, d in enumerate(dets):
+        x[t, :len(d[1])] = d[1]; y[t, :len(d[2])] = d[2]
+    cnt = np.array([len(d[0]) for d in dets], np.int32)
+    P = dict(params.DEPLOYED)
+    table, dmax = transition_cost_table(P)
+    units = np.where(np.isfinite(table), np.rint(table * 1e6), 0).astype(np.int64)
+    grid = hp.Grid(mask, conn8)
+    row_ptr, col, length, gap, cost = hp.build_arcs(dev(x), dev(y), dev(cnt), H, W, dmax, units, grid, 500, conn8)
+    # oracle CSR (per-pair searches on the full grid)
+    offs = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+    rows = [[] for _ in range(int(offs[-1]))]
+    for t in range(F):
+        for g in (1, 2):
+            tb = t + g
+            if tb >= F:
+                continue
+            D = orc.path_matrix(dets[t], dets[tb], H, W, mask, 500, conn8)
+            c = orc.transition_cost(D, g, P['MCF_MISS_RATE'])
+            for i, j in zip(*np.nonzero(c < P['MCF_EDGE_COST_THR'])):
+                a, b = int(offs[t] + i), int(offs[tb] + j)
+                rows[a].append((g, b, int(D[i, j]), orc.arc_cost_int(c[i, j], 3, a, b)))
+    r_ptr, r_col, r_len, r_gap, r_cost = [0], [], [], [], []
+    for r in rows:
+        for g, b, d, ci in sorted(r):
+            r_col.append(b); r_len.append(d); r_gap.append(g); r_cost.append(ci)
+        r_ptr.append(len(r_col))
+    n_det = int(offs[-1])
+    assert np.array_equal(row_ptr[:n_det + 1].cpu().numpy(), np.array(r_ptr))
+    assert np.array_equal(col.cpu().numpy(), np.array(r_col, np.int32))
+    assert np.array_equal(length.cpu().numpy(), np.array(r_len, np.int16))
+    assert np.array_equal(gap.cpu().numpy(), np.array(r_gap, np.uint8))
+    assert np.array_equal(cost.cpu().numpy(), np.array(r_cost, np.int64))
+    assert len(r_col) > 100
