@@ -42,6 +42,9 @@ SIGNATURES = {
                               c_void_p, c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int64)]),
     'axt_hungarian_assoc': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                     c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'axt_hungarian_pairs': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                    c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'axt_chain_tracks': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'axt_arc_cost_int': (c_int64, [c_double, c_int, c_int64, c_int64]),
 }
 

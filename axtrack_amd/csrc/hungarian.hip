@@ -60,10 +60,10 @@ __global__ __launch_bounds__(64) void hungarian_pair_kernel(
     const int *__restrict__ frame_off, int n_frames, int cap, int H, int W, int max_dist, int conn8,
     int dmax, const long *__restrict__ units, long thr_units,
     const int *__restrict__ succ1, const int *__restrict__ pred1,
-    int *__restrict__ succ_out, int *__restrict__ pred_out, int cdim)
+    int *__restrict__ succ_out, int *__restrict__ pred_out, int cdim, int t_first)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
-    const int t = blockIdx.x, tb = t + GAP, lane = threadIdx.x;
+    const int t = t_first + blockIdx.x, tb = t + GAP, lane = threadIdx.x;
     if (tb >= n_frames) return;
     const int n = min(count[t], cap), m = min(count[tb], cap);
     long *v = reinterpret_cast<long *>(hsm);            // [cap] column duals
@@ -271,25 +271,31 @@ __global__ void fill_int_kernel(int *p, long n, int v)
 
 int axt_frame_offsets(const int32_t *d_count, int n_frames, int cap, int32_t *d_off, hipStream_t st);
 
-extern "C" int axt_hungarian_assoc(const int32_t *d_x, const int32_t *d_y, const int32_t *d_count, int n_frames, int cap,
+// Pass 1 / pass 2 for the source frames [t_begin, t_end): links into d_pred = pred1 | pred2, each i32 [n_frames*cap]
+// (predecessor index in frame t-1 / t-2, or -1). Frame-sharded runs give every rank its own range and combine the
+// arrays with one element-wise MAX all-reduce (entries not owned stay -1; the one redundant boundary pair is
+// deterministic, so equal on both ranks). d_work i32 [2*n_frames*cap + n_frames + 1].
+extern "C" int axt_hungarian_pairs(const int32_t *d_x, const int32_t *d_y, const int32_t *d_count, int n_frames, int cap,
                                    int H, int W, int max_dist, int conn8, int max_gap, const int32_t *h_dmax,
-                                   const int64_t *d_cost_units, int64_t thr_units, int32_t *d_work, int32_t *d_track,
-                                   int32_t *d_n_tracks, void *stream)
+                                   const int64_t *d_cost_units, int64_t thr_units, int t_begin, int t_end,
+                                   int32_t *d_pred, int32_t *d_work, void *stream)
 {
-    AXT_REQUIRE(d_x && d_y && d_count && h_dmax && d_cost_units && d_work && d_track && d_n_tracks, "null argument");
-    AXT_REQUIRE(n_frames >= 1 && cap >= 1 && cap <= 2048, "axt_hungarian_assoc: cap %d out of range [1,2048]", cap);
-    AXT_REQUIRE(max_gap == 1 || max_gap == 2, "axt_hungarian_assoc: max_gap must be 1 or 2");
+    AXT_REQUIRE(d_x && d_y && d_count && h_dmax && d_cost_units && d_work && d_pred, "null argument");
+    AXT_REQUIRE(n_frames >= 1 && cap >= 1 && cap <= 2048, "axt_hungarian_pairs: cap %d out of range [1,2048]", cap);
+    AXT_REQUIRE(max_gap == 1 || max_gap == 2, "axt_hungarian_pairs: max_gap must be 1 or 2");
+    AXT_REQUIRE(t_begin >= 0 && t_begin <= t_end && t_end <= n_frames, "axt_hungarian_pairs: bad frame range [%d,%d)", t_begin, t_end);
     hipStream_t st = (hipStream_t)stream;
     const long slots = (long)n_frames * cap;
-    // d_work: succ1 | pred1 | succ2 | pred2 [slots each] | frame_off [n_frames+1]
-    int *succ1 = d_work, *pred1 = succ1 + slots, *succ2 = pred1 + slots, *pred2 = succ2 + slots;
-    int *frame_off = pred2 + slots;
-    hipLaunchKernelGGL(fill_int_kernel, dim3((unsigned)((4 * slots + 255) / 256)), dim3(256), 0, st, succ1, 4 * slots, -1);
+    int *pred1 = d_pred, *pred2 = d_pred + slots;
+    int *succ1 = d_work, *succ2 = succ1 + slots, *frame_off = succ2 + slots;
+    hipLaunchKernelGGL(fill_int_kernel, dim3((unsigned)((2 * slots + 255) / 256)), dim3(256), 0, st, succ1, 2 * slots, -1);
+    AXT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fill_int_kernel, dim3((unsigned)((2 * slots + 255) / 256)), dim3(256), 0, st, pred1, 2 * slots, -1);
     AXT_LAUNCH_CHECK();
     int rc = axt_frame_offsets(d_count, n_frames, cap, frame_off, st);
     if (rc) return rc;
     const size_t lds_base = (size_t)cap * (3 * 8 + 8 * 4 + 2) + 8 + (size_t)(max_dist + 2) * 8;
-    AXT_REQUIRE(lds_base <= 160 * 1024, "axt_hungarian_assoc: cap %d needs %zu bytes of LDS", cap, lds_base);
+    AXT_REQUIRE(lds_base <= 160 * 1024, "axt_hungarian_pairs: cap %d needs %zu bytes of LDS", cap, lds_base);
     // pairs with at most cdim x cdim detections keep their cost matrix in LDS (72 KiB) instead of recomputing it
     int cdim = cap < 96 ? cap : 96;
     if (lds_base + (size_t)cdim * cdim * 8 > 160 * 1024) cdim = 0;
@@ -300,24 +306,37 @@ extern "C" int axt_hungarian_assoc(const int32_t *d_x, const int32_t *d_y, const
         AXT_CHECK_HIP(hipFuncSetAttribute((const void *)hungarian_pair_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    if (n_frames > 1) {
-        hipLaunchKernelGGL(hungarian_pair_kernel<1>, dim3(n_frames - 1), dim3(64), lds, st, d_x, d_y, d_count, frame_off,
+    // pass 2 of source frame t needs pass 1 of the pairs (t, t+1) and (t+1, t+2): pass 1 runs one frame further
+    const int e1 = (max_gap == 2 ? t_end + 1 : t_end) < n_frames - 1 ? (max_gap == 2 ? t_end + 1 : t_end) : n_frames - 1;
+    if (e1 > t_begin) {
+        hipLaunchKernelGGL(hungarian_pair_kernel<1>, dim3(e1 - t_begin), dim3(64), lds, st, d_x, d_y, d_count, frame_off,
                            n_frames, cap, H, W, max_dist, conn8, h_dmax[0], (const long *)d_cost_units, (long)thr_units,
-                           (const int *)nullptr, (const int *)nullptr, succ1, pred1, cdim);
+                           (const int *)nullptr, (const int *)nullptr, succ1, pred1, cdim, t_begin);
         AXT_LAUNCH_CHECK();
     }
-    if (max_gap == 2 && n_frames > 2) {
-        hipLaunchKernelGGL(hungarian_pair_kernel<2>, dim3(n_frames - 2), dim3(64), lds, st, d_x, d_y, d_count, frame_off,
+    const int e2 = t_end < n_frames - 2 ? t_end : n_frames - 2;
+    if (max_gap == 2 && e2 > t_begin) {
+        hipLaunchKernelGGL(hungarian_pair_kernel<2>, dim3(e2 - t_begin), dim3(64), lds, st, d_x, d_y, d_count, frame_off,
                            n_frames, cap, H, W, max_dist, conn8, h_dmax[1],
                            (const long *)d_cost_units + (max_dist + 1), (long)thr_units, (const int *)succ1,
-                           (const int *)pred1, succ2, pred2, cdim);
+                           (const int *)pred1, succ2, pred2, cdim, t_begin);
         AXT_LAUNCH_CHECK();
     }
-    // chain numbering: succ1/succ2 are no longer needed and serve as ping-pong buffers
+    return AXT_OK;
+}
+
+// Chains of links -> trajectory ids numbered by (first frame, index). d_pred as written by axt_hungarian_pairs
+// (after the all-reduce in sharded runs); d_work i32 [2*n_frames*cap]; d_track i32 [n_frames*cap]; d_n_tracks i32 [1].
+extern "C" int axt_chain_tracks(const int32_t *d_count, int n_frames, int cap, const int32_t *d_pred, int32_t *d_work,
+                                int32_t *d_track, int32_t *d_n_tracks, void *stream)
+{
+    AXT_REQUIRE(d_count && d_pred && d_work && d_track && d_n_tracks && n_frames >= 1 && cap >= 1, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const long slots = (long)n_frames * cap;
+    const int *pred1 = d_pred, *pred2 = d_pred + slots;
     const unsigned nb = (unsigned)((slots + 255) / 256);
-    int *ra = succ1, *rb = succ2;
-    hipLaunchKernelGGL(chain_init_kernel, dim3(nb), dim3(256), 0, st, d_count, n_frames, cap, (const int *)pred1,
-                       (const int *)pred2, ra);
+    int *ra = d_work, *rb = d_work + slots;
+    hipLaunchKernelGGL(chain_init_kernel, dim3(nb), dim3(256), 0, st, d_count, n_frames, cap, pred1, pred2, ra);
     AXT_LAUNCH_CHECK();
     for (int span = 1; span < n_frames; span *= 2) {
         hipLaunchKernelGGL(chain_jump_kernel, dim3(nb), dim3(256), 0, st, (const int *)ra, rb, slots);
@@ -329,4 +348,19 @@ extern "C" int axt_hungarian_assoc(const int32_t *d_x, const int32_t *d_y, const
     hipLaunchKernelGGL(chain_assign_kernel, dim3(nb), dim3(256), 0, st, (const int *)ra, (const int *)rb, d_track, slots);
     AXT_LAUNCH_CHECK();
     return AXT_OK;
+}
+
+// Both steps for a whole timelapse on one GPU. d_work i32 [4*n_frames*cap + n_frames + 1].
+extern "C" int axt_hungarian_assoc(const int32_t *d_x, const int32_t *d_y, const int32_t *d_count, int n_frames, int cap,
+                                   int H, int W, int max_dist, int conn8, int max_gap, const int32_t *h_dmax,
+                                   const int64_t *d_cost_units, int64_t thr_units, int32_t *d_work, int32_t *d_track,
+                                   int32_t *d_n_tracks, void *stream)
+{
+    AXT_REQUIRE(d_work && n_frames >= 1 && cap >= 1, "bad argument");
+    const long slots = (long)n_frames * cap;
+    int32_t *pred = d_work, *work = d_work + 2 * slots;
+    int rc = axt_hungarian_pairs(d_x, d_y, d_count, n_frames, cap, H, W, max_dist, conn8, max_gap, h_dmax, d_cost_units,
+                                 thr_units, 0, n_frames, pred, work, stream);
+    if (rc) return rc;
+    return axt_chain_tracks(d_count, n_frames, cap, pred, work, d_track, d_n_tracks, stream);
 }

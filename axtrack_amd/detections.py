@@ -108,9 +108,14 @@ class AxonDetections(object):
         all-gather (RCCL over xGMI on GPUs) gives every rank the detections of the whole
         timelapse, in rank order, before the global flow solve. Blocks must have equal length."""
         from .sharded import all_gather_detections
+        import torch.distributed as dist
+        local = int(self.d_count.shape[0])
         self.d_conf, self.d_x, self.d_y, self.d_count = all_gather_detections(
             self.d_conf, self.d_x, self.d_y, self.d_count, group)
         self._host, self._det_tables = None, None
+        if dist.is_initialized() and dist.get_world_size(group) > 1:
+            r = dist.get_rank(group)
+            self._shard = (r * local, (r + 1) * local, group)       # this rank's frames within the gathered arrays
 
     def _host_dets(self):
         """(count i32 [F], conf f32 [F,cap], x, y) on the host, fetched once."""
@@ -231,6 +236,7 @@ class AxonDetections(object):
                 k = np.nonzero((x[f, :cnt[f]] == ax) & (y[f, :cnt[f]] == ay))[0][0]   # exact anchor match (:804-808)
                 track[offs[f] + k] = int(name[-3:])
         self._track_flat, self._offs = track, offs
+        self._d_track = None
         self._solved, self._ided_tables = True, list(tables)
 
     def astar_dists(self):
@@ -271,17 +277,20 @@ class AxonDetections(object):
         units = np.where(np.isfinite(table), np.rint(table * 1e6), 0).astype(np.int64)
         mode = P.get('ASSOCIATION', 'mcf')
         masked = self.dataset.mask2d is not None
+        shard = getattr(self, '_shard', None)           # set by gather_detections(): solve only this rank's frame pairs
         if mode == 'hungarian':
             if masked:
                 raise NotImplementedError("ASSOCIATION='hungarian' supports all-ones masks only; use 'mcf'")
             track, n_tracks = hp.hungarian_assoc(self.d_x, self.d_y, self.d_count, self.dataset.sizey,
                                                  self.dataset.sizex, dmax, units,
                                                  int(np.rint(P['MCF_EDGE_COST_THR'] * 1e6)),
-                                                 self.max_px_assoc_dist, self.conn8)
+                                                 self.max_px_assoc_dist, self.conn8,
+                                                 *((shard[0], shard[1]), shard[2]) if shard else ())
             cnt = self._host_dets()[0]
             track_h = track.cpu().numpy()
             valid = np.arange(track_h.shape[1])[None, :] < cnt[:, None]
             self._track_flat = track_h[valid]
+            self._d_track = track
             self._offs = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
             self.n_ids, self.mcf_total_cost = int(n_tracks.item()), None
             return True
@@ -312,6 +321,7 @@ class AxonDetections(object):
         nxt, track, n_tracks, total = res
         self.mcf_total_cost, self.n_ids = total, n_tracks
         self._track_flat, self._offs = track, offs
+        self._d_track = None
         return True
 
     def ided_arrays(self):
@@ -326,28 +336,50 @@ class AxonDetections(object):
 
     def _agg_all_IDed_dets(self):
         """AxonDetections.py:825-842, including (by default) its frame-label quirk: labels are
-        column_position//3, so frames after one without IDed detections are labelled one too low."""
+        column_position//3, so frames after one without IDed detections are labelled one too low.
+
+        The table is dense [n_ids, 3*frames] f64 with NaN where an axon is absent -- its size grows with
+        frames x ids, so it is filled on the GPU (one fill + three scatters) and copied once into pinned host
+        memory, which the DataFrame then wraps without another copy."""
         F = len(self)
-        frame, tid, conf, x, y = self.ided_arrays()
-        n_ids = int(tid.max()) + 1 if len(tid) else 0
-        if len(tid) and np.bincount(tid, minlength=n_ids).min() == 0:
-            ids = np.unique(tid)                               # ids with gaps (adopted from a cache)
-            row = np.searchsorted(ids, tid)
+        dev = self.device
+        track = self._track_dev()                                   # i32 [F,cap], -1 = no ID / empty slot
+        sel = track >= 0
+        frame = torch.arange(F, device=dev).unsqueeze(1).expand_as(track)[sel]
+        tid = track[sel].long()
+        n_ids = int(tid.max().item()) + 1 if tid.numel() else 0
+        ids = np.arange(n_ids)
+        if tid.numel() and int(torch.bincount(tid, minlength=n_ids).min().item()) == 0:
+            uniq, row = torch.unique(tid, return_inverse=True)      # ids with gaps (adopted from a cache)
+            ids = uniq.cpu().numpy()
         else:
-            ids, row = np.arange(n_ids), tid
+            row = tid
         if self.reproduce_label_quirk:
-            present = np.zeros(F, bool)
-            present[frame] = True
-            slot_of_frame = np.cumsum(present) - 1          # frames without IDs vanish from the concat (:831)
+            present = torch.zeros(F, dtype=torch.long, device=dev)
+            present[frame] = 1
+            slot = torch.cumsum(present, 0) - 1                     # frames without IDs vanish from the concat (:831)
         else:
-            slot_of_frame = np.arange(F)
-        vals = np.full((len(ids), 3 * F), np.nan)
-        s = 3 * slot_of_frame[frame]
-        vals[row, s] = x
-        vals[row, s + 1] = y
-        vals[row, s + 2] = conf
-        df = pd.DataFrame(vals, index=_axon_index(ids), columns=_ided_columns(F), copy=False)
-        return df
+            slot = torch.arange(F, device=dev)
+        col = 3 * slot[frame]
+        vals = torch.full((len(ids), 3 * F), float('nan'), dtype=torch.float64, device=dev)
+        vals[row, col] = self.d_x[sel].double()
+        vals[row, col + 1] = self.d_y[sel].double()
+        vals[row, col + 2] = self.d_conf[sel].double()
+        host = torch.empty(vals.shape, dtype=torch.float64, pin_memory=True)
+        host.copy_(vals)
+        return pd.DataFrame(host.numpy(), index=_axon_index(ids), columns=_ided_columns(F), copy=False)
+
+    def _track_dev(self):
+        """Trajectory id of every detection slot on the device, i32 [F,cap] (-1: none)."""
+        t = getattr(self, '_d_track', None)
+        if t is None:
+            cnt = self._host_dets()[0]
+            cap = self.d_conf.shape[1]
+            full = np.full((len(cnt), cap), -1, np.int32)
+            valid = np.arange(cap)[None, :] < cnt[:, None]
+            full[valid] = self._track_flat
+            t = self._d_track = torch.from_numpy(full).to(self.device)
+        return t
 
 
 _COLUMNS_CACHE = {}

@@ -259,23 +259,34 @@ def build_arcs(x, y, count, H, W, dmax, cost_units=None, mask=None, max_dist=MAX
     return row_ptr, col[:n], length[:n], gap[:n], (cost[:n] if cost is not None else None)
 
 
-def hungarian_assoc(x, y, count, H, W, dmax, cost_units, thr_units, max_dist=MAX_PX_ASSOC_DIST, conn8=False):
+def hungarian_assoc(x, y, count, H, W, dmax, cost_units, thr_units, max_dist=MAX_PX_ASSOC_DIST, conn8=False,
+                    frame_range=None, group=None):
     """Frame-to-frame Hungarian association (BASELINE config 3) of a whole timelapse on the GPU.
+    frame_range=(a, b): this rank solves only the pairs of source frames a..b-1; the link arrays are then
+    combined over `group` with one MAX all-reduce and every rank numbers the chains (frame-sharded runs).
     Returns (track i32 [F,cap] device tensor, n_tracks device tensor [1])."""
     n_frames, cap = x.shape
     max_gap = len(dmax)
     dev = x.device
     h_dmax = np.ascontiguousarray(dmax, np.int32)
     cu = torch.as_tensor(np.ascontiguousarray(cost_units, np.int64)).to(dev)
-    work = torch.empty((4 * n_frames * cap + n_frames + 1,), dtype=torch.int32, device=dev)
+    slots = n_frames * cap
+    pred = torch.empty((2 * slots,), dtype=torch.int32, device=dev)
+    work = torch.empty((2 * slots + n_frames + 1,), dtype=torch.int32, device=dev)
     track = torch.empty((n_frames, cap), dtype=torch.int32, device=dev)
     n_tracks = torch.zeros((1,), dtype=torch.int32, device=dev)
+    a, b = (0, n_frames) if frame_range is None else frame_range
     lib = _lib.load()
     with torch.cuda.device(dev):
-        _lib.check(lib.axt_hungarian_assoc(x.data_ptr(), y.data_ptr(), count.data_ptr(), n_frames, cap, H, W,
+        _lib.check(lib.axt_hungarian_pairs(x.data_ptr(), y.data_ptr(), count.data_ptr(), n_frames, cap, H, W,
                                            int(max_dist), int(bool(conn8)), max_gap, h_dmax.ctypes.data,
-                                           cu.data_ptr(), int(thr_units), work.data_ptr(), track.data_ptr(),
-                                           n_tracks.data_ptr(), _stream()), 'axt_hungarian_assoc')
+                                           cu.data_ptr(), int(thr_units), int(a), int(b), pred.data_ptr(),
+                                           work.data_ptr(), _stream()), 'axt_hungarian_pairs')
+        if frame_range is not None:
+            import torch.distributed as dist
+            dist.all_reduce(pred, op=dist.ReduceOp.MAX, group=group)
+        _lib.check(lib.axt_chain_tracks(count.data_ptr(), n_frames, cap, pred.data_ptr(), work.data_ptr(),
+                                        track.data_ptr(), n_tracks.data_ptr(), _stream()), 'axt_chain_tracks')
     return track, n_tracks
 
 

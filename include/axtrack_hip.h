@@ -208,6 +208,18 @@ int axt_hungarian_assoc(const int32_t *d_x, const int32_t *d_y, const int32_t *d
                         const int64_t *d_cost_units, int64_t thr_units, int32_t *d_work,
                         int32_t *d_track, int32_t *d_n_tracks, void *stream);
 
+/* The two halves of axt_hungarian_assoc, for frame-sharded runs: every rank solves the frame pairs of its own
+ * source frames [t_begin, t_end) into d_pred = pred1 | pred2 (i32 [2, n_frames*cap], predecessor index in frame
+ * t-1 / t-2 or -1; entries of other ranks' frames stay -1), the ranks combine d_pred with one element-wise MAX
+ * all-reduce, then each numbers the chains. d_work: i32 [2*n_frames*cap + n_frames + 1] for the pairs,
+ * i32 [2*n_frames*cap] for the chains. */
+int axt_hungarian_pairs(const int32_t *d_x, const int32_t *d_y, const int32_t *d_count, int n_frames, int cap,
+                        int H, int W, int max_dist, int conn8, int max_gap, const int32_t *h_dmax,
+                        const int64_t *d_cost_units, int64_t thr_units, int t_begin, int t_end,
+                        int32_t *d_pred, int32_t *d_work, void *stream);
+int axt_chain_tracks(const int32_t *d_count, int n_frames, int cap, const int32_t *d_pred, int32_t *d_work,
+                     int32_t *d_track, int32_t *d_n_tracks, void *stream);
+
 /* Integer arc cost used by the flow network: round(cost * 1e6) << 16 | hash16(kind, a, b).
  * kind 0 entry, 1 exit, 2 observation, 3 transition. The low 16 bits make the optimum unique
  * (DESIGN.md "Unpinned third-party semantics"). */
