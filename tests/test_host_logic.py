@@ -130,3 +130,51 @@ def test_mcf_infeasible_and_argument_errors():
     rc = lib.axt_mcf_solve(1, z.ctypes.data, z.ctypes.data, z.ctypes.data, rp.ctypes.data, bad_col.ctypes.data,
                            z.ctypes.data, 0, 1, out.ctypes.data, out.ctypes.data, ctypes.byref(n), ctypes.byref(tot))
     assert rc == -22 and b'forward in time' in lib.axt_last_error()
+
+
+def test_flow_solver_fast_and_general_paths_agree_at_full_size(monkeypatch):
+    """The detections of the C3 bench timelapse (252 frames, 19 340 detections, captured from the GPU path into
+    tests/data/c3_dets.npz): the assignment-form solver and the successive-shortest-path solver must return the same
+    optimum and the same trajectories on the full 553 k-arc network."""
+    from axtrack_amd.detections import transition_cost_table, _arc_cost_int_vec
+    d = np.load(os.path.join(ROOT, 'tests', 'data', 'c3_dets.npz'))
+    cnt = d['count']
+    F = len(cnt)
+    X = [d['x'][t, :cnt[t]].astype(np.int64) for t in range(F)]
+    Y = [d['y'][t, :cnt[t]].astype(np.int64) for t in range(F)]
+    table, dmax = transition_cost_table(params.DEPLOYED)
+    offs = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+    tails, heads, gaps, lens = [], [], [], []
+    for t in range(F):
+        inb_a = (X[t] >= 0) & (X[t] < 512) & (Y[t] >= 0) & (Y[t] < 512)
+        for g in (1, 2):
+            tb = t + g
+            if tb >= F:
+                continue
+            dx = np.abs(X[t][:, None] - X[tb][None]); dy = np.abs(Y[t][:, None] - Y[tb][None])
+            inb = inb_a[:, None] & ((X[tb] >= 0) & (X[tb] < 512) & (Y[tb] >= 0) & (Y[tb] < 512))[None]
+            D = dx + dy + 1
+            i, j = np.nonzero((D <= dmax[g - 1]) & (dx * dx + dy * dy < 250000) & inb)
+            tails.append(offs[t] + i); heads.append(offs[tb] + j); gaps.append(np.full(len(i), g)); lens.append(D[i, j])
+    a, b, g, L = (np.concatenate(v) for v in (tails, heads, gaps, lens))
+    order = np.lexsort((b, g, a))
+    a, b, g, L = a[order], b[order], g[order], L[order]
+    cost = _arc_cost_int_vec(np.where(g == 1, table[0][L], table[1][L]), 3, a, b)
+    n = int(offs[-1])
+    row_ptr = np.zeros(n + 1, np.int64)
+    row_ptr[1:] = np.cumsum(np.bincount(a, minlength=n))
+    assert len(b) == 553073
+    conf = np.concatenate([d['conf'][t, :cnt[t]] for t in range(F)]).astype(np.float64)
+    obs = orc.observation_cost(orc.cap_conf(conf))
+    k = np.arange(n)
+    obs_i, en_i, ex_i = (_arc_cost_int_vec(obs, 2, k, 0), _arc_cost_int_vec(np.full(n, 2.0), 0, k, 0),
+                         _arc_cost_int_vec(np.full(n, 2.0), 1, k, 0))
+    fast = hp.mcf_solve(obs_i, en_i, ex_i, row_ptr, b, cost, 5, 450)
+    monkeypatch.setenv('AXT_MCF_FORCE_SSP', '1')
+    slow = hp.mcf_solve(obs_i, en_i, ex_i, row_ptr, b, cost, 5, 450)
+    assert fast[2] == slow[2] == 63 and fast[3] == slow[3]
+    assert np.array_equal(fast[0], slow[0]) and np.array_equal(fast[1], slow[1])
+    # a flow bound that the unconstrained optimum violates exercises the fallback from the fast path
+    monkeypatch.delenv('AXT_MCF_FORCE_SSP')
+    capped = hp.mcf_solve(obs_i, en_i, ex_i, row_ptr, b, cost, 5, 40)
+    assert capped[2] == 40 and capped[3] > fast[3]
