@@ -512,3 +512,17 @@ def test_build_arcs_masked_grid_matches_oracle(conn8):
     assert np.array_equal(gap.cpu().numpy(), np.array(r_gap, np.uint8))
     assert np.array_equal(cost.cpu().numpy(), np.array(r_cost, np.int64))
     assert len(r_col) > 100
+
+
+def test_cnn_on_frame_width_not_multiple_of_four(detector, weights):
+    """W = 701, H = 530: the first conv's aligned 16-byte staging cannot be used (rows are not 16-byte aligned and the
+    right-edge tile is 189 px wide); the per-float path must give the same result as the oracle on the zero-padded
+    tile stack."""
+    frames = synth.synth_frames(6, 530, 701, seed=17)
+    fr = dev(frames)
+    keep = hp.tile_occupancy(fr)
+    assert keep == [(0, 0), (0, 1), (1, 0), (1, 1)]
+    y = detector.detect_frames(fr, keep).cpu().numpy()
+    for t in range(2):
+        ref = orc.cnn_forward(weights, orc.frame_tile_stack(frames, t, keep))
+        np.testing.assert_allclose(y[t], ref, atol=CNN_ATOL, rtol=CNN_RTOL)
