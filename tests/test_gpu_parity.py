@@ -526,3 +526,31 @@ def test_cnn_on_frame_width_not_multiple_of_four(detector, weights):
     for t in range(2):
         ref = orc.cnn_forward(weights, orc.frame_tile_stack(frames, t, keep))
         np.testing.assert_allclose(y[t], ref, atol=CNN_ATOL, rtol=CNN_RTOL)
+
+
+def test_end_to_end_detections_against_oracle_cnn(weights):
+    """Whole detection path (HIP CNN included) against the oracle's own CNN on 40 frames: the two f32 forward passes
+    differ by ~1e-6, which can flip an anchor by one pixel when the pre-rounding value sits on a .5 boundary or move a
+    confidence across the 0.55 floor. Everything else must be identical: every HIP detection has an oracle twin within
+    1 px whose confidence agrees to 1e-5, except confidences within 1e-5 of the floor."""
+    frames = synth.synth_frames(44, 512, 512, seed=23)
+    P = params.load_parameters()
+    P['ASSOCIATION'] = 'hungarian'
+    ad = _run_inference(frames, weights, P)
+    cnt, conf, x, y = ad._host_dets()
+    ref = orc.detect_dataset(frames, weights)
+    exact = 0
+    for t, (rc, rx, ry) in enumerate(ref):
+        n = int(cnt[t])
+        mine = {(int(a), int(b)): float(c) for a, b, c in zip(x[t, :n], y[t, :n], conf[t, :n])}
+        theirs = {(int(a), int(b)): float(c) for a, b, c in zip(rx, ry, rc)}
+        exact += len(set(mine) & set(theirs))
+        for (a, b), c in mine.items():
+            if (a, b) in theirs:
+                assert abs(theirs[(a, b)] - c) < 1e-5
+                continue
+            near = [(abs(a - a2) + abs(b - b2), c2) for (a2, b2), c2 in theirs.items() if abs(a - a2) <= 1 and abs(b - b2) <= 1]
+            assert (near and abs(min(near)[1] - c) < 1e-5) or abs(c - 0.55) < 1e-5, f'frame {t}: detection {(a, b, c)} has no oracle twin'
+        assert abs(len(mine) - len(theirs)) <= 1
+    total = int(cnt.sum())
+    assert exact >= 0.995 * total, f'only {exact}/{total} detections identical'
