@@ -1,13 +1,15 @@
 // Detector forward pass for gfx950 (MI355X): YOLO_AXTrack (reference axtrack/machinelearning/model.py:20-125)
 // as f32-in / f32-accumulate MFMA kernels.
 //
-//   conv3x3_mfma   implicit-GEMM 3x3 convolution (pad 1, stride 1|2) + folded BatchNorm + LeakyReLU(0.1)
-//                  (+ fused MaxPool2d(2,2)); the input patch and a K-chunk of the weights are staged in LDS,
-//                  v_mfma_f32_16x16x4_f32 accumulates 16 pixels x 16 channels per instruction.
-//                  The first layer reads the 5-frame temporal stack straight from the timelapse
-//                  (fuses Timelapse.get_frametiles_stack, Timelapse.py:111-125,150-157).
-//   gemm_mfma      split-K GEMM for the three linear layers, partial slabs reduced in a fixed order
-//                  (bit-reproducible) by reduce_bias_act (+ Sigmoid).
+//   conv3x3_mfma     stride-1 implicit-GEMM 3x3 convolution + folded BatchNorm + LeakyReLU(0.1) (+ fused
+//                    MaxPool2d(2,2)) for conv blocks 2..10: the input patch and a K-chunk of the weights are staged
+//                    in LDS, v_mfma_f32_16x16x4_f32 accumulates 16 pixels x 16 channels per instruction, the next
+//                    chunk's global loads are prefetched into registers behind the MFMAs.
+//   conv3x3_s2_mfma  the two stride-2 blocks: persistent workgroups, every wave its own barrier-free pipeline,
+//                    weights LDS-resident. Block 0 reads the 5-frame temporal stack straight from the timelapse
+//                    (fuses Timelapse.get_frametiles_stack, Timelapse.py:111-125,150-157).
+//   gemm_mfma        split-K GEMM for the three linear layers, partial slabs reduced in a fixed order
+//                    (bit-reproducible) by reduce_bias_act (+ Sigmoid).
 //
 // Numerics: f32 MFMA on gfx950 is a k-ordered chain of f32 FMAs (exact f32, no reduced precision).
 // BatchNorm is folded in f64 at pack time and rounded once to f32.
