@@ -255,195 +255,233 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(
 }
 
 // ------------------------------------------------------------------------------------------------
-// stride-2 conv3x3 (conv blocks 0 and 1): low arithmetic intensity, so data movement decides the speed.
-//   * every WAVE is its own pipeline: it stages the 9 input rows its 4 output rows need (rows of 36 floats starting
-//     3 columns left of the patch, 2*x0 - 4, a multiple of 4: aligned 16-byte global loads and ds_write_b128) into a
-//     wave-private LDS region. The main loop therefore has no workgroup barrier; the waves of a CU drift apart and
-//     the loads, MFMAs and stores of different waves overlap. Halo rows shared by two waves are staged twice (9 rows
-//     instead of 8.25).
+// stride-2 conv3x3 on v_mfma_f32_4x4x1_16b_f32 (conv blocks 0 and 1).
+//   These two layers have narrow N (20 / 40 channels) and, block 0, K = 45: on 16x16x4 tiles 20 pads to 32 and 45 to
+//   48. The 4x4x1 shape (16 independent 4-pixel x 4-channel outer products per instruction, 8 cycles, the same
+//   64 FLOP/clk/SIMD) fits exactly: M = 64 pixels per instruction, N in groups of 4 channels, K one at a time -- a
+//   plain k-ordered FMA chain per output.
+//     A (1 VGPR): lane l = the input value of pixel l for this k; B (1 VGPR): lane l = w[k][4g + l%4];
+//     D (4 VGPRs): lane l, register i = pixel 4*(l/4) + i, channel 4g + l%4  -> 4 consecutive pixels, one float4 store.
+//   * wave tile = 4 output rows x 32 columns (two instructions of 2 rows x 32 px), workgroup tile 16 x 32.
+//   * every WAVE is its own pipeline: it stages the 9 input rows x 68 columns (from 2*x0 - 4, a multiple of 4: aligned
+//     16-byte loads) of its tile into a wave-private LDS region, de-interleaved into an even-column and an odd-column
+//     half per row, so that the stride-2 pixel reads become unit-stride (conflict-free ds_read_b32). No workgroup
+//     barrier in the main loop; the waves of a CU drift apart and their loads, MFMAs and stores overlap.
 //   * the next (tile, chunk)'s loads are issued into registers before the MFMAs of the current one and written to
-//     LDS after them; the zero mask for padding is applied at that store, so nothing touches the loaded registers
-//     (and forces a wait) while the MFMAs run. Workgroups are persistent and walk an XCD-contiguous tile list.
-//   * K is ordered k = c*9 + ky*3 + kx per chunk and addressed through a per-lane offset table, so the four k of one
-//     MFMA step mostly differ in kx: with stride-2 pixel addresses (even banks) the next k lands on the odd banks.
-//   * ALL the layer's weights stay in LDS for the life of the workgroup (staged once, one barrier).
+//     LDS after them. The loads are buffer loads: segments outside the image get an out-of-range offset and the
+//     range check returns the zero padding -- nothing touches the loaded registers before the LDS write, and inside
+//     the image a tile costs no address arithmetic at all. Workgroups are persistent and walk an XCD-contiguous
+//     tile list.
+//   * ALL the layer's weights stay in LDS, [k][j][g] so that a lane fetches its NG weights of one k with b128 reads
+//     (4 distinct addresses per instruction: broadcast, no conflicts).
 //   conv block 0 (FIRST) gathers its 5 channels straight from frames t..t+4 of the timelapse at the tile origin
 //   (fuses Timelapse.get_frametiles_stack, Timelapse.py:111-125,150-157), zero beyond the tile and the frame.
 // ------------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int NPC, int NT, bool FIRST, int WPS>
-__global__ __launch_bounds__(256) void conv3x3_s2_mfma(
+template <int COUT>
+struct GeoS2 {
+    static constexpr int NG = COUT / 4, NGP = (NG + 3) / 4 * 4, NB4 = NGP / 4;
+    static constexpr int PHW = 9, SEGS = 17, RW = 4 * SEGS, HALF = RW / 2, PLANE = PHW * RW;
+    static constexpr int TH = 16, TW = 32;
+};
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOobOffset = 0x80000000u;       // byte offset beyond every descriptor's range: the load returns 0
+constexpr int kBufRecords = 0x7fffffff;
+
+template <int CIN, int COUT, int NPC, bool FIRST>
+__global__ __launch_bounds__(256, 2) void conv3x3_s2_k1(
     const float *__restrict__ in, const float *__restrict__ wpk, const float *__restrict__ bias,
-    float *__restrict__ out, const float *__restrict__ zeros, int Hin, int B,
-    int Hf, int Wf, int t0, int tstep, int item0, int n_tiles, TileList tl)
+    float *__restrict__ out, int Hin, int B,
+    int Hf, int Wf, int t0, int tstep, int item0, int n_tiles, TileList tl, int dbg)
 {
-    constexpr int MT = 4, PHW = 9, RW = 36, PLANE = PHW * RW;        // per wave: 9 rows x 36 floats per channel
-    int rag_jx0 = 0, rag_limx = 0;                                    // only used for ragged (unaligned) frames
-    constexpr int WREGION = NPC * PLANE + 4;                          // + one spare float4 (dummy store target)
-    constexpr int NCHUNK = CIN / NPC;
-    constexpr int KREAL = 9 * NPC, KSTEPS = (KREAL + 3) / 4, KROWS = KSTEPS * 4;
-    constexpr int NPADW = npadw(NT);
-    static_assert(CIN % NPC == 0, "CIN must be a multiple of the chunk");
+    using G = GeoS2<COUT>;
+    constexpr int NG = G::NG, NGP = G::NGP, NB4 = G::NB4, PHW = G::PHW, SEGS = G::SEGS, RW = G::RW, HALF = G::HALF,
+                  PLANE = G::PLANE;
+    constexpr int MT = 2;
+    constexpr int WREGION = NPC * PLANE + 40;                         // + a spare row head (dummy store target)
+    constexpr int NCHUNK = CIN / NPC, KPC = 9 * NPC;
+    static_assert(CIN % NPC == 0 && COUT % 4 == 0, "CIN must be a multiple of the chunk, COUT of 4");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float *patch = smem + wave * WREGION;     // this wave's [NPC][9][36]
-    float *wl = smem + 4 * WREGION;           // [NCHUNK][KROWS][NPADW]  (whole layer, shared)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform, and known to be
+    float *patch = smem + wave * WREGION;     // this wave's [NPC][9][even 34 | odd 34]
+    float *wl = smem + 4 * WREGION;           // [CIN*9][4][NGP]  (whole layer, shared)
+    float *bl = wl + CIN * 9 * 4 * NGP;       // [4][NG] folded bias, channel 4g + j at [j][g]
 
-    const int p = lane & 15, q = lane >> 4;
-    const int tiles_x = Hin / 32, ntile = tiles_x * tiles_x;     // output is Hin/2, tiles of 16
+    const int Hout = Hin / 2;
+    const int tiles_x = Hout / G::TW, ntile = tiles_x * (Hout / G::TH);
     const WorkRange wr = my_work(ntile * B);
 
-    // the layer's weights: once per workgroup
     {
-        constexpr int NW4 = NCHUNK * KROWS * NPADW / 4;
+        constexpr int NW4 = CIN * 9 * 4 * NGP / 4;
         const f32x4 *w4 = reinterpret_cast<const f32x4 *>(wpk);
         f32x4 *l4 = reinterpret_cast<f32x4 *>(wl);
         for (int e = tid; e < NW4; e += 256) l4[e] = w4[e];
+        if (tid < COUT) bl[(tid & 3) * NG + (tid >> 2)] = bias[tid];
     }
     __syncthreads();
     if (wr.begin >= wr.end) return;
 
-    int koff[KSTEPS];
-#pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) {
-        const int k = s * 4 + q;
-        const int kk = k < KREAL ? k : 0;                  // padded k rows carry zero weights
-        koff[s] = (kk / 9) * PLANE + ((kk % 9) / 3) * RW + (kk % 3) + 3;
-    }
-    const int a_base = 2 * p;
-    const int b_base = q * NPADW + p;
+    const int a_base = (lane >> 5) * 2 * RW + (lane & 31);           // pixel (row lane/32, column lane%32) of an instruction
+    const int b_base = (lane & 3) * NGP;
+    const int blk = lane >> 2, jch = lane & 3;                       // result: pixels 4*blk..4*blk+3, channel 4g + jch
+
+    // geometry of the source: channel / row strides in floats, constant for the whole launch
+    const int cstride = FIRST ? Hf * Wf : Hin * Hin, rstride = FIRST ? Wf : Hin;
 
     // staging plan of the wave (float4 granularity): element e = lane + k*64 is (channel c, row r, 4-column segment).
-    // The decomposition is done once; per tile an element costs one add (its offset), a few compares and an
-    // address select: lanes whose segment lies outside the image read a 16-byte block of zeros instead, so zero
-    // padding needs no masking of the loaded data (nothing consumes the loaded registers before the MFMAs).
-    constexpr int NP4 = NPC * PHW * (RW / 4);
+    // The global side is a buffer load: descriptor base = the tile's first staged float (wave-uniform, rebuilt per
+    // tile), per-lane byte offset voff[k] (constant for the launch), chunk offset in the scalar offset. Elements
+    // outside the image get the offset kOobOffset instead: the range check returns zeros (the padding) for them.
+    constexpr int NP4 = NPC * PHW * SEGS;
     constexpr int NPE = (NP4 + 63) / 64;
-    constexpr int DUMMY = NPC * PLANE;                    // the wave's spare float4
-    int loff[NPE], crs[NPE];                 // LDS offset; packed (c << 16 | r << 8 | seg), c = 255 for "no element"
+    constexpr int DUMMY = NPC * PLANE;
+    unsigned lds_off[NPE];                   // LDS byte address of the element's even half
+    unsigned ebits[NPE];                     // (1 << r) | (1 << (PHW + seg)): matched against the tile's valid rows / segments
+    unsigned voff[NPE];
 #pragma unroll
     for (int k = 0; k < NPE; ++k) {
         const int e = lane + k * 64;
-        const int c = e / (PHW * (RW / 4)), rem = e - c * (PHW * (RW / 4));
-        const int r = rem / (RW / 4), seg = rem - r * (RW / 4);
-        loff[k] = e < NP4 ? (c * PLANE + r * RW + 4 * seg) : DUMMY;
-        crs[k] = e < NP4 ? ((c << 16) | (r << 8) | seg) : (255 << 16);
+        const int c = e / (PHW * SEGS), rem = e - c * (PHW * SEGS);
+        const int r = rem / SEGS, seg = rem - r * SEGS;
+        lds_off[k] = (unsigned)(size_t)(patch + (e < NP4 ? (c * PLANE + r * RW + 2 * seg) : DUMMY));
+        ebits[k] = e < NP4 ? (1u << r) | (1u << (PHW + seg)) : 0x80000000u;      // bit 31: never valid
+        voff[k] = (unsigned)(c * cstride + r * rstride + 4 * seg) * 4u;
     }
-    const float *pl[NPE];                    // this step's load addresses
     f32x4 pv[NPE];
 
     int cur_b = 0, cur_y0 = 0, cur_x0 = 0;
-    int nxt_b = 0, nxt_y0 = 0, nxt_x0 = 0, nxt_cstride = 0, nxt_aligned = 0;
+    int nxt_b = 0, nxt_y0 = 0, nxt_x0 = 0;
+    unsigned nxt_valid = 0;
+    __amdgpu_buffer_rsrc_t src_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, 0, 0x00020000);
     auto decode_plan = [&](int w) {
         const int tile = w % ntile;
         nxt_b = w / ntile;
-        nxt_y0 = (tile / tiles_x) * 16;
-        nxt_x0 = (tile % tiles_x) * 16;
-        int lim_y, lim_x, rstride;
+        nxt_y0 = (tile / tiles_x) * G::TH;
+        nxt_x0 = (tile % tiles_x) * G::TW;
+        int lim_y, lim_x;
         long src;
         if constexpr (FIRST) {
             const int item = item0 + nxt_b;
             const int t = t0 + (item / n_tiles) * tstep, k = item % n_tiles;
             const int oy = tl.yx[2 * k] * AXT_TILE, ox = tl.yx[2 * k + 1] * AXT_TILE;
             src = ((long)t * Hf + oy) * Wf + ox;
-            nxt_cstride = Hf * Wf;
-            rstride = Wf;
             lim_y = min(AXT_TILE, Hf - oy);
             lim_x = min(AXT_TILE, Wf - ox);
-            nxt_aligned = (Wf % 4 == 0) && (lim_x % 4 == 0);
         } else {
             src = (long)nxt_b * CIN * Hin * Hin;
-            nxt_cstride = Hin * Hin;
-            rstride = Hin;
             lim_y = Hin;
             lim_x = Hin;
-            nxt_aligned = 1;
         }
         // first staged row of this wave / first staged column (a multiple of 4)
-        const int iy0 = (nxt_y0 + wave * MT) * 2 - 1, jx0 = nxt_x0 * 2 - 4;
-        const float *base = in + src + (long)iy0 * rstride + jx0;
-#pragma unroll
-        for (int k = 0; k < NPE; ++k) {
-            const int c = crs[k] >> 16, r = (crs[k] >> 8) & 255, seg = crs[k] & 255;
-            const int gy = iy0 + r, gx = jx0 + 4 * seg;
-            // aligned images: a segment is entirely inside or entirely outside. Ragged ones (width not a multiple
-            // of 4) take the per-float path in load_chunk and only need the row test here.
-            const bool ok = c < NPC && gy >= 0 && gy < lim_y && (!nxt_aligned || (gx >= 0 && gx + 3 < lim_x));
-            pl[k] = ok ? base + (c * nxt_cstride + r * rstride + 4 * seg) : zeros;
-        }
-        if (!nxt_aligned) { rag_jx0 = jx0; rag_limx = lim_x; }
+        const int iy0 = (nxt_y0 + wave * 4) * 2 - 1, jx0 = nxt_x0 * 2 - 4;
+        src_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in) + (src + (long)iy0 * rstride + jx0), 0,
+                                                     (dbg & 4) ? 0 : kBufRecords, 0x00020000);
+        // rows r with 0 <= iy0 + r < lim_y and segments with 0 <= jx0 + 4 seg, jx0 + 4 seg + 3 < lim_x (widths are
+        // multiples of 4: a segment is entirely inside or entirely outside), as one scalar bit set
+        const int r_lo = max(0, -iy0), r_hi = min(PHW, lim_y - iy0);
+        const int s_lo = max(0, -jx0 / 4), s_hi = min(SEGS, (lim_x - jx0) / 4);
+        const unsigned rows = r_hi > r_lo ? ((1u << r_hi) - 1u) & ~((1u << r_lo) - 1u) : 0u;
+        const unsigned segs = s_hi > s_lo ? ((1u << s_hi) - 1u) & ~((1u << s_lo) - 1u) : 0u;
+        nxt_valid = rows | (segs << PHW);
     };
     auto load_chunk = [&](int chunk) {
-        const long coff = (long)chunk * NPC * nxt_cstride;
-        if (nxt_aligned) {
+        const int soff = chunk * NPC * cstride * 4;
 #pragma unroll
-            for (int k = 0; k < NPE; ++k)
-                pv[k] = *reinterpret_cast<const f32x4 *>(pl[k] == zeros ? zeros : pl[k] + coff);
-        } else {
-#pragma unroll
-            for (int k = 0; k < NPE; ++k) {
-                const int gx = rag_jx0 + 4 * (crs[k] & 255);
-                f32x4 v;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bool ok = pl[k] != zeros && gx + j >= 0 && gx + j < rag_limx;
-                    v[j] = ok ? pl[k][coff + j] : 0.f;
-                }
-                pv[k] = v;
-            }
+        for (int k = 0; k < NPE; ++k) {
+            const unsigned off = (ebits[k] & nxt_valid) == ebits[k] ? voff[k] : kOobOffset;
+            pv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(src_rsrc, (int)off, soff, 0));
         }
     };
     auto store_chunk = [&]() {
+        // The compiler does not count the LDS operations issued from asm; lgkmcnt has 4 bits, so they are drained
+        // before more than 12 are in flight and before compiler-generated LDS reads follow.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int k = 0; k < NPE; ++k) *reinterpret_cast<f32x4 *>(patch + loff[k]) = pv[k];
+        for (int k = 0; k < NPE; ++k) {
+            // two ds_write2_b32 straight from the loaded registers (the compiler would first shuffle them into
+            // pairs for ds_write2_b64: 4 moves per element). Even columns, then odd columns.
+            asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" ::"v"(lds_off[k]), "v"(pv[k][0]), "v"(pv[k][2]) : "memory");
+            asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(lds_off[k]), "v"(pv[k][1]), "v"(pv[k][3]),
+                         "n"(HALF), "n"(HALF + 1) : "memory");
+            if (k % 6 == 5 || k == NPE - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
     };
-    float bias_v[NT];
-    load_bias<COUT, NT>(bias, 0, p, bias_v);
-
-    f32x4 acc[MT][NT];
+    // results leave through a buffer store: per-lane offset constant, everything tile-dependent in the scalar offset
+    const __amdgpu_buffer_rsrc_t dst_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(out, 0, (dbg & 1) ? 0 : B * COUT * Hout * Hout * 4, 0x00020000);
+    const int st_voff = (jch * Hout * Hout + (blk >> 3) * Hout + (blk & 7) * 4) * 4;
+    // the accumulators start at the folded bias (kept in LDS, [jch][g]): out = lrelu(bias + sum_k w_k x_k), k ascending
+    f32x4 acc[MT][NG];
+    auto reset_acc = [&](int g) {
+        const float bv = bl[jch * NG + g];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m) acc[m][g] = f32x4{bv, bv, bv, bv};
+    };
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < NG; ++g) reset_acc(g);
 
+    // epilogue of a finished tile: LeakyReLU on the accumulators, one 16-byte store per (row pair, channel group),
+    // accumulators back to the bias
+    auto write_tile = [&](int b, int y0, int x0) {
+        const int tile_soff = (((b * COUT) * Hout + y0 + wave * 4) * Hout + x0) * 4;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                f32x4 v = acc[m][g];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], v[i] * 0.1f);          // LeakyReLU(0.1)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), dst_rsrc, st_voff,
+                                                       tile_soff + (4 * g * Hout + 2 * m) * Hout * 4, 0);
+            }
+            reset_acc(g);
+        }
+    };
+
+    // Order of one step: [wait for this step's loads] LDS writes -> results of the tile finished in the previous
+    // step out -> next step's loads issued -> MFMAs. The stores are thus always OLDER than the loads a step waits
+    // for (vmcnt counts both): no step waits for a store to be acknowledged, and the stores drain behind the MFMAs.
     int w = wr.begin, chunk = 0;
     decode_plan(w);
     cur_b = nxt_b; cur_y0 = nxt_y0; cur_x0 = nxt_x0;
     load_chunk(0);
-    const int Hout = Hin / 2;
+    bool out_pending = false;
+    int out_b = 0, out_y0 = 0, out_x0 = 0;
 #pragma unroll 1
     for (;;) {
         // LDS accesses of one wave execute in order: the reads of the previous step are done before these writes
         store_chunk();
+        if (out_pending) write_tile(out_b, out_y0, out_x0);
         const bool last_chunk = (chunk == NCHUNK - 1);
         const bool has_next = w + wr.step < wr.end;
-        if (!last_chunk) {
-            load_chunk(chunk + 1);
-        } else if (has_next) {
-            decode_plan(w + wr.step);
-            load_chunk(0);
-        }
-        const float *wc = wl + chunk * KROWS * NPADW;
+        if (last_chunk && has_next) decode_plan(w + wr.step);
+        if (!last_chunk || has_next) load_chunk(last_chunk ? 0 : chunk + 1);     // ONE load site: one register set
+        const float *wc = wl + chunk * KPC * 4 * NGP + b_base;
+        if (!(dbg & 2))
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            float a[MT], bw[NT];
+        for (int k = 0; k < KPC; ++k) {
+            const int c = k / 9, ky = (k % 9) / 3, kx = k % 3;
+            // input column 2x + kx - 1: kx = 0 -> odd half at x - 1, kx = 1 -> even half at x, kx = 2 -> odd half at x
+            // (both halves start two columns left of the tile)
+            const int kxoff = kx == 0 ? HALF + 1 : kx == 1 ? 2 : HALF + 2;
+            float a[MT];
+            f32x4 bq[NB4];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) a[m] = patch[a_base + koff[s] + m * 2 * RW];
+            for (int m = 0; m < MT; ++m) a[m] = patch[a_base + c * PLANE + (4 * m + ky) * RW + kxoff];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) bw[n] = wc[b_base + s * 4 * NPADW + n * 16];
+            for (int i = 0; i < NB4; ++i) bq[i] = *reinterpret_cast<const f32x4 *>(wc + k * 4 * NGP + 4 * i);
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bw[n], acc[m][n], 0, 0, 0);
+                for (int g = 0; g < NG; ++g)
+                    acc[m][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[m], bq[g / 4][g % 4], acc[m][g], 0, 0, 0);
         }
+        out_pending = last_chunk;
         if (last_chunk) {
-            conv_epilogue<COUT, false, MT, NT>(acc, bias_v, out, cur_b, 0, cur_y0, cur_x0, wave, p, q, Hout, Hout);
+            out_b = cur_b; out_y0 = cur_y0; out_x0 = cur_x0;
             if (!has_next) break;
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
             w += wr.step;
             cur_b = nxt_b; cur_y0 = nxt_y0; cur_x0 = nxt_x0;
             chunk = 0;
@@ -451,6 +489,22 @@ __global__ __launch_bounds__(256) void conv3x3_s2_mfma(
             ++chunk;
         }
     }
+    write_tile(out_b, out_y0, out_x0);
+}
+
+// rows [n rows of w floats] -> rows of `pitch` floats (a multiple of 4), zero-filled beyond w
+__global__ void repitch_kernel(const float *__restrict__ in, int w, int pitch, long n4, float *__restrict__ out)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int p4 = pitch / 4;
+    const long row = i / p4;
+    const int x = (int)(i - row * p4) * 4;
+    const float *src = in + row * w + x;
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = x + j < w ? src[j] : 0.f;
+    *reinterpret_cast<f32x4 *>(out + row * pitch + x) = v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -542,7 +596,7 @@ __global__ void reduce_bias_act(const float *__restrict__ slab, int S, int M, in
 // host side
 // ------------------------------------------------------------------------------------------------
 struct ConvPlan { int cch, nt, ngroups; };
-static const ConvPlan kPlan[8] = {{5, 2, 1}, {5, 3, 1}, {8, 5, 1}, {8, 5, 1}, {8, 5, 1}, {8, 5, 1}, {8, 5, 1}, {8, 5, 2}};
+static const ConvPlan kPlan[8] = {{5, 2, 1}, {4, 3, 1}, {8, 5, 1}, {8, 5, 1}, {8, 5, 1}, {8, 5, 1}, {8, 5, 1}, {8, 5, 2}};
 
 constexpr int kChunkA = 16;       // tile-forwards per launch for conv blocks 0-2 (activations fit the Infinity Cache)
 constexpr int kChunkB = 32;       // tile-forwards per launch for conv blocks 3-4 (64x64 maps: 1024 workgroups per launch)
@@ -558,7 +612,8 @@ struct axt_detector {
     float *d_bfc[3] = {};
     float *d_act[8] = {};       // activations after conv block i (chunk-sized for i < 4)
     float *d_slab = nullptr, *d_fc1 = nullptr, *d_fc2 = nullptr;
-    float *d_zeros = nullptr;   // 64 bytes of zeros: the address out-of-image lanes load from
+    float *d_pad = nullptr;     // frames re-pitched to a multiple of 4 floats per row (only for such timelapses)
+    size_t pad_cap = 0;
     size_t bytes = 0;
     // optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg)
     bool profiling = false;
@@ -613,19 +668,21 @@ int dev_alloc(axt_detector *d, T **p, size_t n)
     return AXT_OK;
 }
 
-// Packs one conv block: folds BN (f64), lays weights out as [group][chunk][krow][NPADW].
-// krow order inside a chunk, stride-1 layers: ((ky*3+kx) * CCH/4 + cg) * 4 + kk  <->  channel chunk*CCH + cg*4 + kk
-// stride-2 layers (conv3x3_s2_mfma): krow = c*9 + ky*3 + kx with c the channel inside the chunk (45 rows, padded to 48).
+// Packs one conv block: folds BN (f64).
+// stride-1 layers (conv3x3_mfma): [group][chunk][krow][NPADW], krow inside a chunk =
+//   ((ky*3+kx) * CCH/4 + cg) * 4 + kk  <->  channel chunk*CCH + cg*4 + kk
+// stride-2 layers (conv3x3_s2_k1): [k = ci*9 + ky*3 + kx][j][NGP], channel 4g + j at position g.
 void pack_conv(int li, const float *w, const float *b, const float *gamma, const float *beta,
                const float *mean, const float *var, std::vector<float> &wp, std::vector<float> &bp)
 {
     const ConvSpec &cs = kConv[li];
     const ConvPlan &pl = kPlan[li];
     const int NPADW = npadw(pl.nt);
-    const bool first = cs.stride == 2;          // table-ordered K
+    const bool s2 = cs.stride == 2;
     const int nchunk = cs.cin / pl.cch;
-    const int krows = first ? ((9 * pl.cch + 3) / 4) * 4 : 9 * pl.cch;
-    wp.assign((size_t)pl.ngroups * nchunk * krows * NPADW, 0.f);
+    const int krows = 9 * pl.cch;
+    const int ngp = (cs.cout / 4 + 3) / 4 * 4;
+    wp.assign(s2 ? (size_t)cs.cin * 9 * 4 * ngp : (size_t)pl.ngroups * nchunk * krows * NPADW, 0.f);
     bp.assign(cs.cout, 0.f);
     for (int co = 0; co < cs.cout; ++co) {
         const double sc = (double)gamma[co] / sqrt((double)var[co] + 1e-5);
@@ -635,16 +692,13 @@ void pack_conv(int li, const float *w, const float *b, const float *gamma, const
             for (int ky = 0; ky < 3; ++ky)
                 for (int kx = 0; kx < 3; ++kx) {
                     const float v = (float)((double)w[(((size_t)co * cs.cin + ci) * 3 + ky) * 3 + kx] * sc);
-                    int chunk, krow;
-                    if (first) {
-                        chunk = ci / pl.cch;
-                        krow = (ci % pl.cch) * 9 + ky * 3 + kx;
+                    if (s2) {
+                        wp[(((size_t)ci * 9 + ky * 3 + kx) * 4 + co % 4) * ngp + co / 4] = v;
                     } else {
-                        chunk = ci / pl.cch;
-                        const int c = ci % pl.cch;
-                        krow = ((ky * 3 + kx) * (pl.cch / 4) + c / 4) * 4 + c % 4;
+                        const int chunk = ci / pl.cch, c = ci % pl.cch;
+                        const int krow = ((ky * 3 + kx) * (pl.cch / 4) + c / 4) * 4 + c % 4;
+                        wp[(((size_t)grp * nchunk + chunk) * krows + krow) * NPADW + col] = v;
                     }
-                    wp[(((size_t)grp * nchunk + chunk) * krows + krow) * NPADW + col] = v;
                 }
     }
 }
@@ -677,31 +731,35 @@ int launch_conv(const float *in, const float *w, const float *bias, float *out, 
     return AXT_OK;
 }
 
-template <int CIN, int COUT, int NPC, int NT, bool FIRST, int WPS>
-int launch_conv_s2(const float *in, const float *w, const float *bias, float *out, const float *zeros, int Hin, int B,
+template <int CIN, int COUT, int NPC, bool FIRST>
+int launch_conv_s2(const float *in, const float *w, const float *bias, float *out, int Hin, int B,
                    hipStream_t st, int Hf = 0, int Wf = 0, int t0 = 0, int tstep = 1, int item0 = 0, int n_tiles = 1,
                    const TileList *tl = nullptr)
 {
-    auto kern = conv3x3_s2_mfma<CIN, COUT, NPC, NT, FIRST, WPS>;
-    constexpr int KROWS = ((9 * NPC + 3) / 4) * 4;
-    constexpr size_t lds = (size_t)(4 * (NPC * 9 * 36 + 4) + (CIN / NPC) * KROWS * npadw(NT)) * sizeof(float);
+    auto kern = conv3x3_s2_k1<CIN, COUT, NPC, FIRST>;
+    using G = GeoS2<COUT>;
+    constexpr size_t lds = (size_t)(4 * (NPC * G::PLANE + 40) + CIN * 9 * 4 * G::NGP + COUT) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         AXT_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    AXT_REQUIRE(Hin % 32 == 0, "conv: map size %d not a multiple of the tile", Hin);
+    AXT_REQUIRE(Hin % 64 == 0, "conv: map size %d not a multiple of the tile", Hin);
+    AXT_REQUIRE(!FIRST || Wf % 4 == 0, "conv: frame pitch %d not a multiple of 4", Wf);
+    // buffer addressing: offsets inside one tile's source window and inside the output of one launch are 32-bit
+    AXT_REQUIRE(!FIRST || (double)Hf * Wf * 5 * 4 < 2.0e9, "conv: frames of %d x %d are too large", Hf, Wf);
+    AXT_REQUIRE((double)B * COUT * (Hin / 2) * (Hin / 2) * 4 < 2.0e9, "conv: batch of %d is too large for one launch", B);
     TileList dummy;
     dummy.n = 0;
-    const int nwork = (Hin / 32) * (Hin / 32) * B;
+    const int nwork = (Hin / 2 / G::TH) * (Hin / 2 / G::TW) * B;
     static int per_cu = 0;                      // resident workgroups per CU for this kernel (registers + LDS)
     if (per_cu == 0) {
         int n = 0;
         AXT_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)kern, 256, lds));
         per_cu = n < 1 ? 1 : (n > 8 ? 8 : n);
     }
-    hipLaunchKernelGGL(kern, dim3(persistent_grid(nwork, per_cu)), dim3(256), lds, st, in, w, bias, out, zeros, Hin, B, Hf, Wf,
-                       t0, tstep, item0, n_tiles, tl ? *tl : dummy);
+    hipLaunchKernelGGL(kern, dim3(persistent_grid(nwork, per_cu)), dim3(256), lds, st, in, w, bias, out, Hin, B, Hf, Wf,
+                       t0, tstep, item0, n_tiles, tl ? *tl : dummy, getenv("AXT_DBG") ? atoi(getenv("AXT_DBG")) : 0);
     AXT_LAUNCH_CHECK();
     return AXT_OK;
 }
@@ -733,13 +791,37 @@ int run_front_a(axt_detector *d, const float *frames, int Hf, int Wf, int t0, in
     int rc;
     {
         ProfSpan ps(d, st, 0, nb);
-        if ((rc = launch_conv_s2<5, 20, 5, 2, true, 4>(frames, d->d_wconv[0], d->d_bconv[0], d->d_act[0], d->d_zeros, 512, nb, st, Hf, Wf,
-                                                    t0, tstep, item0, n_tiles, &tl))) return rc;
+        const float *src = frames;
+        int pitch = Wf, t_first = 0;
+        if (Wf % 4 != 0) {
+            // rows that are not 16-byte aligned: copy the frames this launch reads into a buffer whose pitch is
+            // (the zero columns it adds are what the tile padding would read anyway)
+            t_first = t0 + (item0 / n_tiles) * tstep;
+            const int t_last = t0 + ((item0 + nb - 1) / n_tiles) * tstep + AXT_IN_CH - 1;
+            const int nf = t_last - t_first + 1;
+            pitch = (Wf + 3) / 4 * 4;
+            const size_t need = (size_t)nf * Hf * pitch;
+            if (need > d->pad_cap) {
+                AXT_CHECK_HIP(hipStreamSynchronize(st));
+                (void)hipFree(d->d_pad);
+                d->d_pad = nullptr;
+                d->pad_cap = 0;
+                AXT_CHECK_HIP(hipMalloc((void **)&d->d_pad, need * sizeof(float)));
+                d->pad_cap = need;
+            }
+            const long n4 = (long)nf * Hf * (pitch / 4);
+            hipLaunchKernelGGL(repitch_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
+                               frames + (size_t)t_first * Hf * Wf, Wf, pitch, n4, d->d_pad);
+            AXT_LAUNCH_CHECK();
+            src = d->d_pad;
+        }
+        rc = launch_conv_s2<5, 20, 5, true>(src, d->d_wconv[0], d->d_bconv[0], d->d_act[0], 512, nb, st, Hf, pitch,
+                                            t0 - t_first, tstep, item0, n_tiles, &tl);
+        if (rc) return rc;
     }
     {
         ProfSpan ps(d, st, 1, nb);
-        if ((rc = launch_conv_s2<20, 40, 5, 3, false, 3>(d->d_act[0], d->d_wconv[1], d->d_bconv[1], d->d_act[1], d->d_zeros, 256, nb,
-                                                      st))) return rc;
+        if ((rc = launch_conv_s2<20, 40, 4, false>(d->d_act[0], d->d_wconv[1], d->d_bconv[1], d->d_act[1], 256, nb, st))) return rc;
     }
     {
         ProfSpan ps(d, st, 2, nb);
@@ -894,11 +976,6 @@ int axt_detector_create(const float *const *h_tensors, int n_tensors, int max_ba
     if (!rc) rc = dev_alloc(d, &d->d_slab, (size_t)kFc1Split * max_batch * kFc);
     if (!rc) rc = dev_alloc(d, &d->d_fc1, (size_t)max_batch * kFc);
     if (!rc) rc = dev_alloc(d, &d->d_fc2, (size_t)max_batch * kFc);
-    if (!rc) rc = dev_alloc(d, &d->d_zeros, (size_t)16);
-    if (!rc && hipMemset(d->d_zeros, 0, 64) != hipSuccess) {
-        axt_set_error("hipMemset failed");
-        rc = AXT_EHIP;
-    }
     if (!rc && hipDeviceSynchronize() != hipSuccess) {
         axt_set_error("device synchronize failed after upload");
         rc = AXT_EHIP;
@@ -926,13 +1003,18 @@ void axt_detector_destroy(axt_detector *d)
     (void)hipFree(d->d_slab);
     (void)hipFree(d->d_fc1);
     (void)hipFree(d->d_fc2);
-    (void)hipFree(d->d_zeros);
+    (void)hipFree(d->d_pad);
     for (auto &sp : d->spans) {
         (void)hipEventDestroy(sp.a);
         (void)hipEventDestroy(sp.b);
     }
     for (hipEvent_t e : d->free_events) (void)hipEventDestroy(e);
     delete d;
+}
+
+int axt_debug_act(axt_detector *d, int idx, float *h, size_t n)   // TEMPORARY debugging aid
+{
+    return hipMemcpy(h, d->d_act[idx], n * 4, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 
 size_t axt_detector_device_bytes(const axt_detector *d) { return d ? d->bytes : 0; }

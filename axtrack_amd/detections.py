@@ -235,8 +235,8 @@ class AxonDetections(object):
             for name, ax, ay in zip(t.index, tx, ty):
                 k = np.nonzero((x[f, :cnt[f]] == ax) & (y[f, :cnt[f]] == ay))[0][0]   # exact anchor match (:804-808)
                 track[offs[f] + k] = int(name[-3:])
-        self._track_flat, self._offs = track, offs
-        self._d_track = None
+        self._track_flat_cache, self._d_track = track, None
+        self.n_ids = None                                           # unknown: ids are whatever the cache holds
         self._solved, self._ided_tables = True, list(tables)
 
     def astar_dists(self):
@@ -286,12 +286,7 @@ class AxonDetections(object):
                                                  int(np.rint(P['MCF_EDGE_COST_THR'] * 1e6)),
                                                  self.max_px_assoc_dist, self.conn8,
                                                  *((shard[0], shard[1]), shard[2]) if shard else ())
-            cnt = self._host_dets()[0]
-            track_h = track.cpu().numpy()
-            valid = np.arange(track_h.shape[1])[None, :] < cnt[:, None]
-            self._track_flat = track_h[valid]
-            self._d_track = track
-            self._offs = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+            self._d_track, self._track_flat_cache = track, None       # host copies are made on first use only
             self.n_ids, self.mcf_total_cost = int(n_tracks.item()), None
             return True
         if mode != 'mcf':
@@ -320,9 +315,22 @@ class AxonDetections(object):
             return False
         nxt, track, n_tracks, total = res
         self.mcf_total_cost, self.n_ids = total, n_tracks
-        self._track_flat, self._offs = track, offs
-        self._d_track = None
+        self._track_flat_cache, self._d_track = track, None
         return True
+
+    @property
+    def _offs(self):
+        """Start of every frame in the flat (frame-major) detection numbering, i64 [F+1]."""
+        return np.concatenate([[0], np.cumsum(self._host_dets()[0])]).astype(np.int64)
+
+    @property
+    def _track_flat(self):
+        """Trajectory id of every detection in flat numbering on the host, i32 [n_det] (-1: none)."""
+        if getattr(self, '_track_flat_cache', None) is None:
+            cnt = self._host_dets()[0]
+            track_h = self._d_track.cpu().numpy()
+            self._track_flat_cache = track_h[np.arange(track_h.shape[1])[None, :] < cnt[:, None]]
+        return self._track_flat_cache
 
     def ided_arrays(self):
         """(frame i32, id i32, conf f32, x i32, y i32) of every IDed detection, frame-major."""
@@ -330,8 +338,9 @@ class AxonDetections(object):
         frame_of = np.repeat(np.arange(len(cnt)), cnt)
         k = np.arange(len(frame_of))
         idx_in = k - self._offs[frame_of]
-        sel = self._track_flat >= 0
-        return (frame_of[sel], self._track_flat[sel], conf[frame_of[sel], idx_in[sel]], x[frame_of[sel], idx_in[sel]],
+        track = self._track_flat
+        sel = track >= 0
+        return (frame_of[sel], track[sel], conf[frame_of[sel], idx_in[sel]], x[frame_of[sel], idx_in[sel]],
                 y[frame_of[sel], idx_in[sel]])
 
     def _agg_all_IDed_dets(self):
@@ -339,35 +348,20 @@ class AxonDetections(object):
         column_position//3, so frames after one without IDed detections are labelled one too low.
 
         The table is dense [n_ids, 3*frames] f64 with NaN where an axon is absent -- its size grows with
-        frames x ids, so it is filled on the GPU (one fill + three scatters) and copied once into pinned host
-        memory, which the DataFrame then wraps without another copy."""
-        F = len(self)
-        dev = self.device
+        frames x ids, so it is filled on the GPU (axt_ided_table) and copied once into pinned host memory,
+        which the DataFrame then wraps without another copy."""
         track = self._track_dev()                                   # i32 [F,cap], -1 = no ID / empty slot
-        sel = track >= 0
-        frame = torch.arange(F, device=dev).unsqueeze(1).expand_as(track)[sel]
-        tid = track[sel].long()
-        n_ids = int(tid.max().item()) + 1 if tid.numel() else 0
-        ids = np.arange(n_ids)
-        if tid.numel() and int(torch.bincount(tid, minlength=n_ids).min().item()) == 0:
-            uniq, row = torch.unique(tid, return_inverse=True)      # ids with gaps (adopted from a cache)
+        n_ids, ids, id_row = self.n_ids, None, None
+        if n_ids is None:                                           # adopted from a cache: ids may have gaps
+            uniq = torch.unique(track[track >= 0])
             ids = uniq.cpu().numpy()
-        else:
-            row = tid
-        if self.reproduce_label_quirk:
-            present = torch.zeros(F, dtype=torch.long, device=dev)
-            present[frame] = 1
-            slot = torch.cumsum(present, 0) - 1                     # frames without IDs vanish from the concat (:831)
-        else:
-            slot = torch.arange(F, device=dev)
-        col = 3 * slot[frame]
-        vals = torch.full((len(ids), 3 * F), float('nan'), dtype=torch.float64, device=dev)
-        vals[row, col] = self.d_x[sel].double()
-        vals[row, col + 1] = self.d_y[sel].double()
-        vals[row, col + 2] = self.d_conf[sel].double()
-        host = torch.empty(vals.shape, dtype=torch.float64, pin_memory=True)
-        host.copy_(vals)
-        return pd.DataFrame(host.numpy(), index=_axon_index(ids), columns=_ided_columns(F), copy=False)
+            n_ids = int(ids[-1]) + 1 if len(ids) else 0
+            id_row = torch.full((max(n_ids, 1),), -1, dtype=torch.int32, device=self.device)
+            id_row[uniq.long()] = torch.arange(len(ids), dtype=torch.int32, device=self.device)
+        vals = hp.ided_table(track, self.d_conf, self.d_x, self.d_y, self.d_count, n_ids, self.reproduce_label_quirk,
+                             id_row, None if ids is None else len(ids))
+        return pd.DataFrame(vals, index=_axon_index(np.arange(n_ids) if ids is None else ids),
+                            columns=_ided_columns(len(self)), copy=False)
 
     def _track_dev(self):
         """Trajectory id of every detection slot on the device, i32 [F,cap] (-1: none)."""
@@ -377,7 +371,7 @@ class AxonDetections(object):
             cap = self.d_conf.shape[1]
             full = np.full((len(cnt), cap), -1, np.int32)
             valid = np.arange(cap)[None, :] < cnt[:, None]
-            full[valid] = self._track_flat
+            full[valid] = self._track_flat_cache
             t = self._d_track = torch.from_numpy(full).to(self.device)
         return t
 

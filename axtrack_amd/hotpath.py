@@ -290,6 +290,25 @@ def hungarian_assoc(x, y, count, H, W, dmax, cost_units, thr_units, max_dist=MAX
     return track, n_tracks
 
 
+def ided_table(track, conf, x, y, count, n_ids, label_quirk=True, id_row=None, n_rows=None):
+    """IDed_dets_all's values (AxonDetections.py:825-842) as a pinned host f64 array [n_rows, 3*F]: filled on the
+    GPU (axt_ided_table), copied across once. id_row: optional i32 device tensor id -> row for ids with gaps."""
+    n_frames, cap = x.shape
+    dev = x.device
+    n_rows = int(n_ids if n_rows is None else n_rows)
+    table = torch.empty((n_rows, 3 * n_frames), dtype=torch.float64, device=dev)
+    work = torch.empty((n_frames,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().axt_ided_table(track.data_ptr(), conf.data_ptr(), x.data_ptr(), y.data_ptr(),
+                                              count.data_ptr(), n_frames, cap, int(n_ids),
+                                              id_row.data_ptr() if id_row is not None else None, n_rows,
+                                              int(bool(label_quirk)), work.data_ptr(), table.data_ptr(), _stream()),
+                   'axt_ided_table')
+    host = torch.empty(table.shape, dtype=torch.float64, pin_memory=True)
+    host.copy_(table)
+    return host.numpy()
+
+
 def arc_cost_int(cost, kind, a, b):
     return int(_lib.load().axt_arc_cost_int(float(cost), int(kind), int(a), int(b)))
 

@@ -220,6 +220,19 @@ int axt_hungarian_pairs(const int32_t *d_x, const int32_t *d_y, const int32_t *d
 int axt_chain_tracks(const int32_t *d_count, int n_frames, int cap, const int32_t *d_pred, int32_t *d_work,
                      int32_t *d_track, int32_t *d_n_tracks, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * IDed_dets_all (AxonDetections._agg_all_IDed_dets, AxonDetections.py:825-842) as a dense f64
+ * table [n_rows, 3*n_frames] on the device: columns 3*slot(f)+{0,1,2} = anchor_x, anchor_y, conf of
+ * the detection of frame f that carries the row's identity, NaN elsewhere. slot(f) = f, or with
+ * label_quirk != 0 the rank of f among the frames that have an IDed detection (the reference's
+ * concat drops the others, :831, and labels the rest by position).
+ * d_track i32 [n_frames, cap] (-1 = no identity), d_id_row: NULL (row = id, n_rows == n_ids) or
+ * i32 [n_ids] id -> row (-1 = drop); d_work i32 [n_frames] scratch. Asynchronous.
+ * ------------------------------------------------------------------------------------------ */
+int axt_ided_table(const int32_t *d_track, const float *d_conf, const int32_t *d_x, const int32_t *d_y,
+                   const int32_t *d_count, int n_frames, int cap, int n_ids, const int32_t *d_id_row, int n_rows,
+                   int label_quirk, int32_t *d_work, double *d_table, void *stream);
+
 /* Integer arc cost used by the flow network: round(cost * 1e6) << 16 | hash16(kind, a, b).
  * kind 0 entry, 1 exit, 2 observation, 3 transition. The low 16 bits make the optimum unique
  * (DESIGN.md "Unpinned third-party semantics"). */

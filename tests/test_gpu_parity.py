@@ -242,7 +242,7 @@ def test_ided_dets_all_reproduces_the_references_table(golden, weights):
     track = np.full(int(offs[-1]), -1, np.int32)
     for tid, f, k in a['traj']:
         track[offs[f] + k] = tid
-    ad._track_flat, ad._offs, ad._d_track = track, offs, None
+    ad._track_flat_cache, ad._d_track, ad.n_ids = track, None, None     # as adopted from a cache: ids unknown
     df = ad._agg_all_IDed_dets()
     assert list(df.index) == list(a['ided_all_index'])
     assert [float(c[0]) for c in df.columns] == list(a['ided_all_cols_frame'])
