@@ -354,6 +354,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_k1(
     int cur_b = 0, cur_y0 = 0, cur_x0 = 0;
     int nxt_b = 0, nxt_y0 = 0, nxt_x0 = 0;
     unsigned nxt_valid = 0;
+    const float *nxt_base = in;
     __amdgpu_buffer_rsrc_t src_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, 0, 0x00020000);
     auto decode_plan = [&](int w) {
         const int tile = w % ntile;
@@ -376,6 +377,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_k1(
         }
         // first staged row of this wave / first staged column (a multiple of 4)
         const int iy0 = (nxt_y0 + wave * 4) * 2 - 1, jx0 = nxt_x0 * 2 - 4;
+        nxt_base = in + (src + (long)iy0 * rstride + jx0);
         src_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in) + (src + (long)iy0 * rstride + jx0), 0,
                                                      (dbg & 4) ? 0 : kBufRecords, 0x00020000);
         // rows r with 0 <= iy0 + r < lim_y and segments with 0 <= jx0 + 4 seg, jx0 + 4 seg + 3 < lim_x (widths are
@@ -391,10 +393,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_k1(
 #pragma unroll
         for (int k = 0; k < NPE; ++k) {
             const unsigned off = (ebits[k] & nxt_valid) == ebits[k] ? voff[k] : kOobOffset;
+#ifdef AXT_EXP_GLOAD
+            pv[k] = off == kOobOffset ? f32x4{0.f, 0.f, 0.f, 0.f}
+                                      : *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(nxt_base) + off + soff);
+#else
             pv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(src_rsrc, (int)off, soff, 0));
+#endif
         }
     };
     auto store_chunk = [&]() {
+#ifdef AXT_EXP_CSTORE
+#pragma unroll
+        for (int k = 0; k < NPE; ++k) {
+            volatile float *d = (volatile float *)(smem) + (lds_off[k] >> 2);
+            d[0] = pv[k][0]; d[1] = pv[k][2]; d[HALF] = pv[k][1]; d[HALF + 1] = pv[k][3];
+        }
+#else
         // The compiler does not count the LDS operations issued from asm; lgkmcnt has 4 bits, so they are drained
         // before more than 12 are in flight and before compiler-generated LDS reads follow.
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -407,6 +421,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_k1(
                          "n"(HALF), "n"(HALF + 1) : "memory");
             if (k % 6 == 5 || k == NPE - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
+#endif
     };
     // results leave through a buffer store: per-lane offset constant, everything tile-dependent in the scalar offset
     const __amdgpu_buffer_rsrc_t dst_rsrc =
@@ -433,8 +448,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_k1(
                 f32x4 v = acc[m][g];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], v[i] * 0.1f);          // LeakyReLU(0.1)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), dst_rsrc, st_voff,
-                                                       tile_soff + (4 * g * Hout + 2 * m) * Hout * 4, 0);
+                // The tile-dependent part of the address goes into the VECTOR offset on purpose. With it in the scalar
+                // offset hipcc (ROCm 7.2) inserts no wait state between the store and the next write of its data
+                // registers, and on gfx950 a 16-byte buffer store then picks up part of the NEXT group's values
+                // whenever another workgroup shares the CU (measured: ~0.05 % of the outputs wrong).
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), dst_rsrc,
+                                                       st_voff + tile_soff + (4 * g * Hout + 2 * m) * Hout * 4, 0, 0);
             }
             reset_acc(g);
         }
@@ -453,10 +472,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_k1(
     for (;;) {
         // LDS accesses of one wave execute in order: the reads of the previous step are done before these writes
         store_chunk();
-        if (out_pending) write_tile(out_b, out_y0, out_x0);
+        if (out_pending && !(dbg & 16)) write_tile(out_b, out_y0, out_x0);
+        if (dbg & 32) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const bool last_chunk = (chunk == NCHUNK - 1);
         const bool has_next = w + wr.step < wr.end;
         if (last_chunk && has_next) decode_plan(w + wr.step);
+        if (!(dbg & 64))
         if (!last_chunk || has_next) load_chunk(last_chunk ? 0 : chunk + 1);     // ONE load site: one register set
         const float *wc = wl + chunk * KPC * 4 * NGP + b_base;
         if (!(dbg & 2))
@@ -472,15 +493,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_k1(
             for (int m = 0; m < MT; ++m) a[m] = patch[a_base + c * PLANE + (4 * m + ky) * RW + kxoff];
 #pragma unroll
             for (int i = 0; i < NB4; ++i) bq[i] = *reinterpret_cast<const f32x4 *>(wc + k * 4 * NGP + 4 * i);
+#ifdef AXT_EXP_LGKM
+            asm volatile("s_waitcnt lgkmcnt(0)\n s_nop 7" : "+v"(a[0]), "+v"(a[1]), "+v"(bq[0]), "+v"(bq[NB4 - 1]) :: "memory");
+#endif
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int g = 0; g < NG; ++g)
                     acc[m][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[m], bq[g / 4][g % 4], acc[m][g], 0, 0, 0);
         }
+        if (dbg & 64) {
+            if (!last_chunk || has_next) load_chunk(last_chunk ? 0 : chunk + 1);
+        }
         out_pending = last_chunk;
         if (last_chunk) {
             out_b = cur_b; out_y0 = cur_y0; out_x0 = cur_x0;
+            if (dbg & 16) write_tile(out_b, out_y0, out_x0);
             if (!has_next) break;
             w += wr.step;
             cur_b = nxt_b; cur_y0 = nxt_y0; cur_x0 = nxt_x0;
@@ -489,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_k1(
             ++chunk;
         }
     }
-    write_tile(out_b, out_y0, out_x0);
+    if (!(dbg & 16)) write_tile(out_b, out_y0, out_x0);
 }
 
 // rows [n rows of w floats] -> rows of `pitch` floats (a multiple of 4), zero-filled beyond w
@@ -741,7 +769,7 @@ int launch_conv_s2(const float *in, const float *w, const float *bias, float *ou
     constexpr size_t lds = (size_t)(4 * (NPC * G::PLANE + 40) + CIN * 9 * 4 * G::NGP + COUT) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        AXT_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AXT_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds + 8192));
         attr_set = true;
     }
     AXT_REQUIRE(Hin % 64 == 0, "conv: map size %d not a multiple of the tile", Hin);
@@ -758,8 +786,9 @@ int launch_conv_s2(const float *in, const float *w, const float *bias, float *ou
         AXT_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)kern, 256, lds));
         per_cu = n < 1 ? 1 : (n > 8 ? 8 : n);
     }
-    hipLaunchKernelGGL(kern, dim3(persistent_grid(nwork, per_cu)), dim3(256), lds, st, in, w, bias, out, Hin, B, Hf, Wf,
-                       t0, tstep, item0, n_tiles, tl ? *tl : dummy, getenv("AXT_DBG") ? atoi(getenv("AXT_DBG")) : 0);
+    const int dbgv = getenv("AXT_DBG") ? atoi(getenv("AXT_DBG")) : 0;
+    hipLaunchKernelGGL(kern, dim3(persistent_grid(nwork, (dbgv & 128) ? 1 : per_cu)), dim3(256), lds + ((dbgv & 256) ? 8192 : 0), st, in, w, bias, out, Hin, B, Hf, Wf,
+                       t0, tstep, item0, n_tiles, tl ? *tl : dummy, dbgv);
     AXT_LAUNCH_CHECK();
     return AXT_OK;
 }
