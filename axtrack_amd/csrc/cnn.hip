@@ -288,11 +288,11 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned kOobOffset = 0x80000000u;       // byte offset beyond every descriptor's range: the load returns 0
 constexpr int kBufRecords = 0x7fffffff;
 
-template <int CIN, int COUT, int NPC, bool FIRST>
+template <int CIN, int COUT, int NPC, bool FIRST, int PF>
 __global__ __launch_bounds__(256, 2) void conv3x3_s2_k1(
     const float *__restrict__ in, const float *__restrict__ wpk, const float *__restrict__ bias,
     float *__restrict__ out, int Hin, int B,
-    int Hf, int Wf, int t0, int tstep, int item0, int n_tiles, TileList tl, int dbg)
+    int Hf, int Wf, int t0, int tstep, int item0, int n_tiles, TileList tl)
 {
     using G = GeoS2<COUT>;
     constexpr int NG = G::NG, NGP = G::NGP, NB4 = G::NB4, PHW = G::PHW, SEGS = G::SEGS, RW = G::RW, HALF = G::HALF,
@@ -354,7 +354,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_k1(
     int cur_b = 0, cur_y0 = 0, cur_x0 = 0;
     int nxt_b = 0, nxt_y0 = 0, nxt_x0 = 0;
     unsigned nxt_valid = 0;
-    const float *nxt_base = in;
     __amdgpu_buffer_rsrc_t src_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, 0, 0x00020000);
     auto decode_plan = [&](int w) {
         const int tile = w % ntile;
@@ -377,9 +376,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_k1(
         }
         // first staged row of this wave / first staged column (a multiple of 4)
         const int iy0 = (nxt_y0 + wave * 4) * 2 - 1, jx0 = nxt_x0 * 2 - 4;
-        nxt_base = in + (src + (long)iy0 * rstride + jx0);
         src_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in) + (src + (long)iy0 * rstride + jx0), 0,
-                                                     (dbg & 4) ? 0 : kBufRecords, 0x00020000);
+                                                     kBufRecords, 0x00020000);
         // rows r with 0 <= iy0 + r < lim_y and segments with 0 <= jx0 + 4 seg, jx0 + 4 seg + 3 < lim_x (widths are
         // multiples of 4: a segment is entirely inside or entirely outside), as one scalar bit set
         const int r_lo = max(0, -iy0), r_hi = min(PHW, lim_y - iy0);
@@ -393,22 +391,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_k1(
 #pragma unroll
         for (int k = 0; k < NPE; ++k) {
             const unsigned off = (ebits[k] & nxt_valid) == ebits[k] ? voff[k] : kOobOffset;
-#ifdef AXT_EXP_GLOAD
-            pv[k] = off == kOobOffset ? f32x4{0.f, 0.f, 0.f, 0.f}
-                                      : *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(nxt_base) + off + soff);
-#else
             pv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(src_rsrc, (int)off, soff, 0));
-#endif
         }
     };
     auto store_chunk = [&]() {
-#ifdef AXT_EXP_CSTORE
-#pragma unroll
-        for (int k = 0; k < NPE; ++k) {
-            volatile float *d = (volatile float *)(smem) + (lds_off[k] >> 2);
-            d[0] = pv[k][0]; d[1] = pv[k][2]; d[HALF] = pv[k][1]; d[HALF + 1] = pv[k][3];
-        }
-#else
         // The compiler does not count the LDS operations issued from asm; lgkmcnt has 4 bits, so they are drained
         // before more than 12 are in flight and before compiler-generated LDS reads follow.
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -421,11 +407,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_k1(
                          "n"(HALF), "n"(HALF + 1) : "memory");
             if (k % 6 == 5 || k == NPE - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-#endif
     };
     // results leave through a buffer store: per-lane offset constant, everything tile-dependent in the scalar offset
     const __amdgpu_buffer_rsrc_t dst_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(out, 0, (dbg & 1) ? 0 : B * COUT * Hout * Hout * 4, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(out, 0, B * COUT * Hout * Hout * 4, 0x00020000);
     const int st_voff = (jch * Hout * Hout + (blk >> 3) * Hout + (blk & 7) * 4) * 4;
     // the accumulators start at the folded bias (kept in LDS, [jch][g]): out = lrelu(bias + sum_k w_k x_k), k ascending
     f32x4 acc[MT][NG];
@@ -472,43 +457,47 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_k1(
     for (;;) {
         // LDS accesses of one wave execute in order: the reads of the previous step are done before these writes
         store_chunk();
-        if (out_pending && !(dbg & 16)) write_tile(out_b, out_y0, out_x0);
-        if (dbg & 32) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (out_pending) write_tile(out_b, out_y0, out_x0);
         const bool last_chunk = (chunk == NCHUNK - 1);
         const bool has_next = w + wr.step < wr.end;
         if (last_chunk && has_next) decode_plan(w + wr.step);
-        if (!(dbg & 64))
         if (!last_chunk || has_next) load_chunk(last_chunk ? 0 : chunk + 1);     // ONE load site: one register set
         const float *wc = wl + chunk * KPC * 4 * NGP + b_base;
-        if (!(dbg & 2))
+        {
+            // operands of k-step k + PF are fetched from LDS while the MFMAs of k-step k issue (register ring of PF + 1
+            // sets); the group barriers pin that interleave -- left alone the scheduler sinks every read to just
+            // before its first use and each k-step then waits out the LDS latency.
+            float a[PF + 1][MT];
+            f32x4 bq[PF + 1][NB4];
+            auto fetch = [&](int k) {
+                const int c = k / 9, ky = (k % 9) / 3, kx = k % 3, slot = k % (PF + 1);
+                // input column 2x + kx - 1: kx = 0 -> odd half at x - 1, kx = 1 -> even half at x, kx = 2 -> odd half
+                // at x (both halves start two columns left of the tile)
+                const int kxoff = kx == 0 ? HALF + 1 : kx == 1 ? 2 : HALF + 2;
 #pragma unroll
-        for (int k = 0; k < KPC; ++k) {
-            const int c = k / 9, ky = (k % 9) / 3, kx = k % 3;
-            // input column 2x + kx - 1: kx = 0 -> odd half at x - 1, kx = 1 -> even half at x, kx = 2 -> odd half at x
-            // (both halves start two columns left of the tile)
-            const int kxoff = kx == 0 ? HALF + 1 : kx == 1 ? 2 : HALF + 2;
-            float a[MT];
-            f32x4 bq[NB4];
+                for (int m = 0; m < MT; ++m) a[slot][m] = patch[a_base + c * PLANE + (4 * m + ky) * RW + kxoff];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) a[m] = patch[a_base + c * PLANE + (4 * m + ky) * RW + kxoff];
+                for (int i = 0; i < NB4; ++i) bq[slot][i] = *reinterpret_cast<const f32x4 *>(wc + k * 4 * NGP + 4 * i);
+            };
 #pragma unroll
-            for (int i = 0; i < NB4; ++i) bq[i] = *reinterpret_cast<const f32x4 *>(wc + k * 4 * NGP + 4 * i);
-#ifdef AXT_EXP_LGKM
-            asm volatile("s_waitcnt lgkmcnt(0)\n s_nop 7" : "+v"(a[0]), "+v"(a[1]), "+v"(bq[0]), "+v"(bq[NB4 - 1]) :: "memory");
-#endif
+            for (int k = 0; k < PF; ++k) fetch(k);
+            __builtin_amdgcn_sched_group_barrier(0x100, PF * (MT + NB4), 0);   // the ring's head start
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+            for (int k = 0; k < KPC; ++k) {
+                if (k + PF < KPC) fetch(k + PF);
+                const int slot = k % (PF + 1);
 #pragma unroll
-                for (int g = 0; g < NG; ++g)
-                    acc[m][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[m], bq[g / 4][g % 4], acc[m][g], 0, 0, 0);
-        }
-        if (dbg & 64) {
-            if (!last_chunk || has_next) load_chunk(last_chunk ? 0 : chunk + 1);
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+                        acc[m][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[slot][m], bq[slot][g / 4][g % 4], acc[m][g], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, MT + NB4, 0);      // the DS reads of k-step k + PF
+                __builtin_amdgcn_sched_group_barrier(0x008, MT * NG, 0);       // the MFMAs of k-step k
+            }
         }
         out_pending = last_chunk;
         if (last_chunk) {
             out_b = cur_b; out_y0 = cur_y0; out_x0 = cur_x0;
-            if (dbg & 16) write_tile(out_b, out_y0, out_x0);
             if (!has_next) break;
             w += wr.step;
             cur_b = nxt_b; cur_y0 = nxt_y0; cur_x0 = nxt_x0;
@@ -517,7 +506,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_k1(
             ++chunk;
         }
     }
-    if (!(dbg & 16)) write_tile(out_b, out_y0, out_x0);
+    write_tile(out_b, out_y0, out_x0);
 }
 
 // rows [n rows of w floats] -> rows of `pitch` floats (a multiple of 4), zero-filled beyond w
@@ -759,17 +748,17 @@ int launch_conv(const float *in, const float *w, const float *bias, float *out, 
     return AXT_OK;
 }
 
-template <int CIN, int COUT, int NPC, bool FIRST>
+template <int CIN, int COUT, int NPC, bool FIRST, int PF>
 int launch_conv_s2(const float *in, const float *w, const float *bias, float *out, int Hin, int B,
                    hipStream_t st, int Hf = 0, int Wf = 0, int t0 = 0, int tstep = 1, int item0 = 0, int n_tiles = 1,
                    const TileList *tl = nullptr)
 {
-    auto kern = conv3x3_s2_k1<CIN, COUT, NPC, FIRST>;
+    auto kern = conv3x3_s2_k1<CIN, COUT, NPC, FIRST, PF>;
     using G = GeoS2<COUT>;
     constexpr size_t lds = (size_t)(4 * (NPC * G::PLANE + 40) + CIN * 9 * 4 * G::NGP + COUT) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        AXT_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds + 8192));
+        AXT_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     AXT_REQUIRE(Hin % 64 == 0, "conv: map size %d not a multiple of the tile", Hin);
@@ -786,9 +775,8 @@ int launch_conv_s2(const float *in, const float *w, const float *bias, float *ou
         AXT_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)kern, 256, lds));
         per_cu = n < 1 ? 1 : (n > 8 ? 8 : n);
     }
-    const int dbgv = getenv("AXT_DBG") ? atoi(getenv("AXT_DBG")) : 0;
-    hipLaunchKernelGGL(kern, dim3(persistent_grid(nwork, (dbgv & 128) ? 1 : per_cu)), dim3(256), lds + ((dbgv & 256) ? 8192 : 0), st, in, w, bias, out, Hin, B, Hf, Wf,
-                       t0, tstep, item0, n_tiles, tl ? *tl : dummy, dbgv);
+    hipLaunchKernelGGL(kern, dim3(persistent_grid(nwork, per_cu)), dim3(256), lds, st, in, w, bias, out, Hin, B, Hf, Wf,
+                       t0, tstep, item0, n_tiles, tl ? *tl : dummy);
     AXT_LAUNCH_CHECK();
     return AXT_OK;
 }
@@ -844,13 +832,13 @@ int run_front_a(axt_detector *d, const float *frames, int Hf, int Wf, int t0, in
             AXT_LAUNCH_CHECK();
             src = d->d_pad;
         }
-        rc = launch_conv_s2<5, 20, 5, true>(src, d->d_wconv[0], d->d_bconv[0], d->d_act[0], 512, nb, st, Hf, pitch,
+        rc = launch_conv_s2<5, 20, 5, true, 3>(src, d->d_wconv[0], d->d_bconv[0], d->d_act[0], 512, nb, st, Hf, pitch,
                                             t0 - t_first, tstep, item0, n_tiles, &tl);
         if (rc) return rc;
     }
     {
         ProfSpan ps(d, st, 1, nb);
-        if ((rc = launch_conv_s2<20, 40, 4, false>(d->d_act[0], d->d_wconv[1], d->d_bconv[1], d->d_act[1], 256, nb, st))) return rc;
+        if ((rc = launch_conv_s2<20, 40, 4, false, 2>(d->d_act[0], d->d_wconv[1], d->d_bconv[1], d->d_act[1], 256, nb, st))) return rc;
     }
     {
         ProfSpan ps(d, st, 2, nb);
@@ -1039,11 +1027,6 @@ void axt_detector_destroy(axt_detector *d)
     }
     for (hipEvent_t e : d->free_events) (void)hipEventDestroy(e);
     delete d;
-}
-
-int axt_debug_act(axt_detector *d, int idx, float *h, size_t n)   // TEMPORARY debugging aid
-{
-    return hipMemcpy(h, d->d_act[idx], n * 4, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 
 size_t axt_detector_device_bytes(const axt_detector *d) { return d ? d->bytes : 0; }

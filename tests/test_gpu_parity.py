@@ -528,6 +528,22 @@ def test_cnn_on_frame_width_not_multiple_of_four(detector, weights):
         np.testing.assert_allclose(y[t], ref, atol=CNN_ATOL, rtol=CNN_RTOL)
 
 
+def test_cnn_when_workgroups_share_a_cu(detector, weights):
+    """1024x1024 frames, 2 detection frames = 8 tile-forwards: the persistent stride-2 kernels then run two
+    workgroups per CU with two tiles each. A 16-byte buffer store whose data registers were rewritten too early
+    corrupted ~0.05 % of conv block 0's outputs in exactly this situation (and only then)."""
+    frames = synth.synth_frames(6, 1024, 1024, seed=29)
+    fr = dev(frames)
+    keep = hp.tile_occupancy(fr)
+    assert len(keep) == 4
+    y = detector.detect_frames(fr, keep).cpu().numpy()
+    y2 = detector.detect_frames(fr, keep).cpu().numpy()
+    assert np.array_equal(y, y2)                              # and it is deterministic
+    for t in range(2):
+        ref = orc.cnn_forward(weights, orc.frame_tile_stack(frames, t, keep))
+        np.testing.assert_allclose(y[t], ref, atol=CNN_ATOL, rtol=CNN_RTOL)
+
+
 def test_end_to_end_detections_against_oracle_cnn(weights):
     """Whole detection path (HIP CNN included) against the oracle's own CNN on 40 frames: the two f32 forward passes
     differ by ~1e-6, which can flip an anchor by one pixel when the pre-rounding value sits on a .5 boundary or move a
