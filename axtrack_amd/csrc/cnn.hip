@@ -134,7 +134,7 @@ struct GeoS1 {
     static constexpr int KSTEPS = 9 * CCH / 4, KROWS = KSTEPS * 4;
 };
 
-template <int CIN, int COUT, bool POOL, int CCH, int NT>
+template <int CIN, int COUT, bool POOL, int CCH, int NT, int PF = 1>
 __global__ __launch_bounds__(256, 2) void conv3x3_mfma(
     const float *__restrict__ in,       // activations [B,CIN,Hin,Hin]
     const float *__restrict__ wpk,      // packed weights [ngroup][nchunk][KROWS][NPADW]
@@ -234,21 +234,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(
         store_chunk();
         __syncthreads();
         if (chunk + 1 < NCHUNK) load_chunk(chunk + 1);
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            float a[MT], bw[NT];
+        // operands of k-step s + PF are fetched from LDS while the MFMAs of k-step s issue (register ring of PF + 1
+        // sets); the group barriers pin that interleave (left alone the scheduler sinks the reads to their first use)
+        float a[PF + 1][MT], bw[PF + 1][NT];
+        auto fetch = [&](int s) {
             constexpr int CG = CCH / 4;
             const int kk = s / CG, cg = s % CG;      // (ky,kx) major, channel group minor
-            const int ky = kk / 3, kx = kk % 3;
+            const int ky = kk / 3, kx = kk % 3, slot = s % (PF + 1);
 #pragma unroll
-            for (int m = 0; m < MT; ++m) a[m] = patch[a_base + cg * 4 * PLANE + (m + ky) * PW + kx];
+            for (int m = 0; m < MT; ++m) a[slot][m] = patch[a_base + cg * 4 * PLANE + (m + ky) * PW + kx];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) bw[n] = wl[b_base + s * 4 * NPADW + n * 16];
+            for (int n = 0; n < NT; ++n) bw[slot][n] = wl[b_base + s * 4 * NPADW + n * 16];
+        };
+#pragma unroll
+        for (int s = 0; s < PF; ++s) fetch(s);
+        __builtin_amdgcn_sched_group_barrier(0x100, PF * (MT + NT), 0);
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            if (s + PF < KSTEPS) fetch(s + PF);
+            const int slot = s % (PF + 1);
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bw[n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[slot][m], bw[slot][n], acc[m][n], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
         }
     }
     conv_epilogue<COUT, POOL, MT, NT>(acc, bias_v, out, b, grp, y0, x0, wave, p, q, Hout, Hout);
