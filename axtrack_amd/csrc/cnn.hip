@@ -18,6 +18,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <vector>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -626,8 +627,12 @@ __global__ void reduce_bias_act(const float *__restrict__ slab, int S, int M, in
 struct ConvPlan { int cch, nt, ngroups; };
 static const ConvPlan kPlan[8] = {{5, 2, 1}, {4, 3, 1}, {8, 5, 1}, {8, 5, 1}, {8, 5, 1}, {8, 5, 1}, {8, 5, 1}, {8, 5, 2}};
 
-constexpr int kChunkA = 16;       // tile-forwards per launch for conv blocks 0-2 (activations fit the Infinity Cache)
-constexpr int kChunkB = 32;       // tile-forwards per launch for conv blocks 3-4 (64x64 maps: 1024 workgroups per launch)
+// Tile-forwards per launch of the front layers. Measured on MI355X (252 tile-forwards): 16/32 -> 6.16 ms, 64/64 ->
+// 5.9 ms, 128/128 -> 5.8 ms, 256/256 -> 6.1 ms for the whole CNN: what matters is that every persistent workgroup of
+// the stride-2 kernels gets several tiles and that launch gaps amortise, not that the activations of one chunk fit
+// the Infinity Cache. 128 items of block-0 output are 0.67 GB.
+constexpr int kChunkA = 128;      // conv blocks 0-2
+constexpr int kChunkB = 128;      // conv blocks 3-4
 constexpr int kFc1Split = 8, kFc2Split = 4, kFc3Split = 4;
 
 }  // namespace
@@ -1000,7 +1005,7 @@ int axt_detector_create(const float *const *h_tensors, int n_tensors, int max_ba
     const size_t per_item[8] = {20u * 256 * 256, 40u * 128 * 128, 80u * 64 * 64, 80u * 64 * 64,
                                 80u * 32 * 32,   80u * 32 * 32,   80u * 16 * 16, 160u * 16 * 16};
     for (int i = 0; i < 8 && !rc; ++i)
-        rc = dev_alloc(d, &d->d_act[i], per_item[i] * (size_t)(i < 2 ? kChunkA : i < 4 ? kChunkB : max_batch));
+        rc = dev_alloc(d, &d->d_act[i], per_item[i] * (size_t)std::min(max_batch, i < 2 ? kChunkA : i < 4 ? kChunkB : max_batch));
     if (!rc) rc = dev_alloc(d, &d->d_slab, (size_t)kFc1Split * max_batch * kFc);
     if (!rc) rc = dev_alloc(d, &d->d_fc1, (size_t)max_batch * kFc);
     if (!rc) rc = dev_alloc(d, &d->d_fc2, (size_t)max_batch * kFc);
