@@ -42,6 +42,10 @@ constexpr int kOutPad = 448;           // 7 x 64
 // ------------------------------------------------------------------------------------------------
 constexpr int npadw(int nt) { return (nt % 2) ? nt * 16 : nt * 16 + 16; }   // row stride == 16 (mod 32)
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOobOffset = 0x80000000u;       // byte offset beyond every descriptor's range: the load returns 0
+constexpr int kBufRecords = 0x7fffffff;
+
 struct TileList { int n; short yx[2 * 256]; };
 
 // Persistent workgroups: the grid is a multiple of 8 and every workgroup walks a strided list of work items
@@ -167,19 +171,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(
     const int tile = w % ntile, rest = w / ntile;
     const int grp = rest % ngroups, b = rest / ngroups;
     const int y0 = (tile / tiles_x) * 16, x0 = (tile % tiles_x) * 16;
-    const long cstride = (long)Hin * Hin;
+    const int cstride = Hin * Hin;
     const int Hout = POOL ? Hin / 2 : Hin;
 
-    // staging plan: element e = tid + k*256 of the patch is (channel c, row r, col). Branch-free: elements past
-    // the patch go to a dummy LDS word, elements outside the image load from a clamped (valid) address and are
-    // zeroed by a select. Per chunk all loads are issued back to back into registers and written to LDS after the
-    // barrier, while the next chunk's loads are already in flight behind the MFMAs (async-STAGE split).
+    // staging plan: element e = tid + k*256 of the patch is (channel c, row r, col). Branch-free: per element one
+    // word, (offset inside the chunk << 12) | LDS offset; elements past the patch go to a dummy LDS word, elements
+    // outside the image carry the offset kOut and are loaded with an out-of-range buffer offset (the range check
+    // returns the zero padding). Both streams are buffer loads: descriptor bases and chunk offsets are scalars, so a
+    // chunk costs no 64-bit address arithmetic. Per chunk all loads are issued back to back into registers and
+    // written to LDS after the barrier, while the next chunk's loads are already in flight behind the MFMAs
+    // (async-STAGE split).
     constexpr int NPE = (CCH * PH * PW + 255) / 256;
     constexpr int NW4 = KROWS * NPADW / 4;
     constexpr int NWE = (NW4 + 255) / 256;
     constexpr int DUMMY = CCH * PLANE - 1;       // last (padding) word of the last plane, never read by the MFMAs
     static_assert(PLANE > PH * PW, "the plane padding provides the dummy word");
-    int loff[NPE], goff[NPE];
+    static_assert(CCH * PLANE <= 4096, "LDS offsets are packed into 12 bits");
+    constexpr int kOut = (1 << 20) - 1;
+    int plan[NPE];
 #pragma unroll
     for (int k = 0; k < NPE; ++k) {
         const int e = tid + k * 256;
@@ -188,28 +197,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(
         const int gy = y0 - 1 + r, gx = x0 - 1 + col;
         const bool in_patch = e < CCH * PH * PW;
         const bool ok = in_patch && gy >= 0 && gy < Hin && gx >= 0 && gx < Hin;
-        loff[k] = in_patch ? c * PLANE + r * PW + col : DUMMY;
-        const int g = c * (int)cstride + gy * Hin + gx;
-        goff[k] = ok ? g : -1;
+        const int g = c * cstride + gy * Hin + gx;
+        plan[k] = ((ok ? g : kOut) << 12) | (in_patch ? c * PLANE + r * PW + col : DUMMY);
     }
     float pv[NPE];
     f32x4 wv[NWE];
-    const float *isrc = in + (long)b * CIN * cstride;
-    const float *wsrc = wpk + (long)grp * NCHUNK * KROWS * NPADW;
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(in) + (long)b * CIN * cstride, 0, kBufRecords, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(wpk) + (long)grp * NCHUNK * KROWS * NPADW, 0, kBufRecords, 0x00020000);
     auto load_chunk = [&](int chunk) {
-        const float *csrc = isrc + (long)chunk * CCH * cstride;
+        const int isoff = chunk * CCH * cstride * 4;
 #pragma unroll
-        for (int k = 0; k < NPE; ++k) pv[k] = csrc[goff[k] < 0 ? 0 : goff[k]];     // masked at store time
-        const f32x4 *w4 = reinterpret_cast<const f32x4 *>(wsrc + (long)chunk * KROWS * NPADW);
+        for (int k = 0; k < NPE; ++k) {
+            const unsigned g = (unsigned)plan[k] >> 12;
+            pv[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, (int)(g == kOut ? kOobOffset : g * 4u), isoff, 0));
+        }
+        const int wsoff = chunk * KROWS * NPADW * 4;
 #pragma unroll
         for (int k = 0; k < NWE; ++k) {
             const int e = tid + k * 256;
-            wv[k] = w4[(NW4 % 256 == 0 || e < NW4) ? e : 0];
+            wv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                  w_rsrc, (NW4 % 256 == 0 || e < NW4) ? e * 16 : (int)kOobOffset, wsoff, 0));
         }
     };
     auto store_chunk = [&]() {
 #pragma unroll
-        for (int k = 0; k < NPE; ++k) patch[loff[k]] = goff[k] < 0 ? 0.f : pv[k];
+        for (int k = 0; k < NPE; ++k) patch[plan[k] & 4095] = pv[k];
         f32x4 *l4 = reinterpret_cast<f32x4 *>(wl);
 #pragma unroll
         for (int k = 0; k < NWE; ++k) {
@@ -295,10 +309,6 @@ struct GeoS2 {
     static constexpr int PHW = 9, SEGS = 17, RW = 4 * SEGS, HALF = RW / 2, PLANE = PHW * RW;
     static constexpr int TH = 16, TW = 32;
 };
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-constexpr unsigned kOobOffset = 0x80000000u;       // byte offset beyond every descriptor's range: the load returns 0
-constexpr int kBufRecords = 0x7fffffff;
 
 template <int CIN, int COUT, int NPC, bool FIRST, int PF>
 __global__ __launch_bounds__(256, 2) void conv3x3_s2_k1(
