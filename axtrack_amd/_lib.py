@@ -38,6 +38,11 @@ SIGNATURES = {
     'axt_build_arcs': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_void_p, ctypes.POINTER(c_int64), c_void_p]),
+    'axt_box_histograms': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                   c_void_p, c_void_p, c_void_p]),
+    'axt_build_arcs_vis': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                   c_int, c_void_p, c_void_p, c_void_p, c_double, c_double, c_double, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_int64), c_void_p]),
     'axt_mcf_solve': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                               c_void_p, c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int64)]),
     'axt_hungarian_assoc': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

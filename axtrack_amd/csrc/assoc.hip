@@ -12,6 +12,9 @@
 // breadth-first search per source (path_bfs.hip).
 #include "axt_common.h"
 
+// every rounding in this file is part of the contract with the CPU restatement: no fused multiply-adds
+#pragma clang fp contract(off)
+
 int axt_path_cost_masked(const int32_t *d_xa, const int32_t *d_ya, int na, const int32_t *d_xb, const int32_t *d_yb,
                          int nb, const uint8_t *d_mask, int H, int W, int max_dist, int conn8, int32_t *d_D,
                          hipStream_t st);
@@ -114,14 +117,41 @@ __global__ void frame_offsets_kernel(const int *__restrict__ count, int n_frames
 // TABLE: path lengths come from the masked-grid BFS pass instead of the closed form.
 // FILL == false: writes the number of admitted targets to cnt[(a_global)*max_gap + g-1].
 // FILL == true : writes the arcs at row_ptr[a_global] + (arcs of smaller gaps) in ascending b.
-template <bool FILL, bool TABLE>
+// VIS (MCF_VIS_SIM_WEIGHT > 0): the transition cost is no longer a table of (D, gap) -- it is
+// -log((1-w) * (1 - D/max) * miss^(gap-1) + w * (1 - bhattacharyya(hist_a, hist_b)) + 1e-6) per pair
+// (mincostflow_models.py:100-118), computed here in f64 with the reference's operation order, and an arc is admitted
+// iff that cost is below the edge threshold. dmax then only bounds the candidates (cost with similarity 1).
+struct VisParams {
+    const float *hist;      // [n_frames, cap, 180] min-max normalised histograms (axt_box_histograms)
+    const double *hsum;     // [n_frames, cap] their bin sums
+    double w, thr, mp[8];   // weight, edge cost threshold, miss_rate^(gap-1)
+};
+
+__device__ __forceinline__ double vis_transition_cost(const VisParams &vp, const float *ha, double sa, const float *hb,
+                                                      double sb, int d, int g, int max_dist)
+{
+    // plain operators: fp contract is off in this file, every operation rounds once, in the reference's order
+    double s12 = 0.0;
+    for (int b = 0; b < 180; ++b) s12 += sqrt((double)ha[b] * (double)hb[b]);
+    double s = sa * sb;
+    s = fabs(s) > 1.1920928955078125e-07 ? 1.0 / sqrt(s) : 1.0;
+    const double t = 1.0 - s12 * s;
+    const double vs = 1.0 - sqrt(t > 0.0 ? t : 0.0);                                  // 1 - cv2.compareHist(...)
+    const double dist = (((double)d / (double)max_dist) - 1.0) * -1.0;                // ((D / max) - 1) * -1
+    if (dist == 0.0) return INFINITY;
+    const double v = (1.0 - vp.w) * dist * vp.mp[g - 1] + vp.w * vs + 1e-6;
+    return -log(v);
+}
+
+template <bool FILL, bool TABLE, bool VIS>
 __global__ __launch_bounds__(256) void arcs_open_kernel(
     const int *__restrict__ x, const int *__restrict__ y, const int *__restrict__ count,
     const int *__restrict__ frame_off, int n_frames, int cap, int H, int W, int max_dist, int conn8, int max_gap,
     const int *__restrict__ dmax, int *__restrict__ cnt, const long *__restrict__ row_ptr,
     int *__restrict__ col, short *__restrict__ len, unsigned char *__restrict__ gapv,
-    const long *__restrict__ cost_units, long *__restrict__ cost, const short *__restrict__ Dtmp)
+    const long *__restrict__ cost_units, long *__restrict__ cost, const short *__restrict__ Dtmp, VisParams vp)
 {
+    __shared__ float ha_s[VIS ? 4 : 1][VIS ? 180 : 1];
     const int t = blockIdx.x;
     const int na = min(count[t], cap);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -140,6 +170,11 @@ __global__ __launch_bounds__(256) void arcs_open_kernel(
                 base = row_ptr[a];
                 for (int gg = 1; gg < g; ++gg) base += cnt[(long)a * max_gap + gg - 1];
             }
+            double sa = 0.0;
+            if (VIS) {                      // this wave's source histogram, read by every lane for every target
+                for (int b = lane; b < 180; b += 64) ha_s[wave][b] = vp.hist[((long)t * cap + i) * 180 + b];
+                sa = vp.hsum[(long)t * cap + i];
+            }
             for (int j0 = 0; j0 < nb; j0 += 64) {
                 const int j = j0 + lane;
                 int d = max_dist;
@@ -151,14 +186,23 @@ __global__ __launch_bounds__(256) void arcs_open_kernel(
                         d = path_len_open(xa, ya, x[(long)tb * cap + j], y[(long)tb * cap + j], H, W, max_dist, conn8);
                     }
                 }
-                const bool ok = (j < nb) && (d <= lim);
+                bool ok = (j < nb) && (d <= lim);
+                double c = 0.0;
+                if (VIS && ok) {
+                    c = vis_transition_cost(vp, ha_s[wave], sa, vp.hist + ((long)tb * cap + j) * 180,
+                                            vp.hsum[(long)tb * cap + j], d, g, max_dist);
+                    ok = c < vp.thr;
+                }
                 const unsigned long long m = __ballot(ok);
                 if (FILL && ok) {
                     const long o = base + total + __popcll(m & ((1ull << lane) - 1ull));
                     col[o] = frame_off[tb] + j;
                     len[o] = (short)d;
                     gapv[o] = (unsigned char)g;
-                    if (cost) cost[o] = arc_cost_int(cost_units[(long)(g - 1) * (max_dist + 1) + d], 3, a, frame_off[tb] + j);
+                    if (cost) {
+                        const long units = VIS ? llrint(c * 1e6) : cost_units[(long)(g - 1) * (max_dist + 1) + d];
+                        cost[o] = arc_cost_int(units, 3, a, frame_off[tb] + j);
+                    }
                 }
                 total += __popcll(m);
             }
@@ -242,10 +286,10 @@ int axt_path_cost(const int32_t *d_xa, const int32_t *d_ya, int na, const int32_
     return AXT_OK;
 }
 
-int axt_build_arcs(const int32_t *d_x, const int32_t *d_y, const int32_t *d_count, int n_frames, int cap,
-                   const axt_grid *grid, int H, int W, int max_dist, int conn8, int max_gap, const int32_t *h_dmax,
-                   int64_t *d_row_ptr, int32_t *d_work, int32_t *d_col, int16_t *d_len, uint8_t *d_gap,
-                   const int64_t *d_cost_units, int64_t *d_cost, int64_t *n_arcs, void *stream)
+static int build_arcs_impl(const int32_t *d_x, const int32_t *d_y, const int32_t *d_count, int n_frames, int cap,
+                           const axt_grid *grid, int H, int W, int max_dist, int conn8, int max_gap, const int32_t *h_dmax,
+                           int64_t *d_row_ptr, int32_t *d_work, int32_t *d_col, int16_t *d_len, uint8_t *d_gap,
+                           const int64_t *d_cost_units, int64_t *d_cost, int64_t *n_arcs, const VisParams *vis, void *stream)
 {
     AXT_REQUIRE(d_x && d_y && d_count && h_dmax && d_row_ptr && d_work && n_arcs, "null argument");
     AXT_REQUIRE(n_frames >= 1 && cap >= 1 && max_gap >= 1 && max_gap <= 8, "bad argument");
@@ -257,7 +301,17 @@ int axt_build_arcs(const int32_t *d_x, const int32_t *d_y, const int32_t *d_coun
     int *dmax = frame_off + n_frames + 1;
     short *Dtmp = reinterpret_cast<short *>(d_work + (((size_t)n_frames * cap * max_gap + n_frames + 1 + max_gap + 3) & ~(size_t)3));
     const dim3 grid_dim(n_frames, 8), block(256);
-    if (d_col == nullptr) {
+    const bool fill = d_col != nullptr;
+    const VisParams vp = vis ? *vis : VisParams{};
+    // the four (table, appearance) variants of one pass
+    auto launch = [&](auto kern) {
+        hipLaunchKernelGGL(kern, grid_dim, block, 0, st, d_x, d_y, d_count, frame_off, n_frames, cap, H, W, max_dist, conn8,
+                           max_gap, dmax, cnt, fill ? (const long *)d_row_ptr : (const long *)nullptr, fill ? d_col : (int *)nullptr,
+                           fill ? d_len : (short *)nullptr, fill ? d_gap : (unsigned char *)nullptr,
+                           fill ? (const long *)d_cost_units : (const long *)nullptr, fill ? (long *)d_cost : (long *)nullptr,
+                           grid ? (const short *)Dtmp : (const short *)nullptr, vp);
+    };
+    if (!fill) {
         AXT_CHECK_HIP(hipMemcpyAsync(dmax, h_dmax, sizeof(int) * max_gap, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(frame_offsets_kernel, dim3(1), dim3(1024), 0, st, d_count, n_frames, cap, frame_off);
         AXT_LAUNCH_CHECK();
@@ -265,16 +319,11 @@ int axt_build_arcs(const int32_t *d_x, const int32_t *d_y, const int32_t *d_coun
             const int rc = axt_masked_distance_table(grid, d_x, d_y, d_count, n_frames, cap, max_dist, max_gap, h_dmax, dmax,
                                                      Dtmp, st);
             if (rc) return rc;
-            hipLaunchKernelGGL((arcs_open_kernel<false, true>), grid_dim, block, 0, st, d_x, d_y, d_count, frame_off, n_frames,
-                               cap, H, W, max_dist, conn8, max_gap, dmax, cnt, (const long *)nullptr, (int *)nullptr,
-                               (short *)nullptr, (unsigned char *)nullptr, (const long *)nullptr, (long *)nullptr,
-                               (const short *)Dtmp);
-        } else {
-            hipLaunchKernelGGL((arcs_open_kernel<false, false>), grid_dim, block, 0, st, d_x, d_y, d_count, frame_off, n_frames,
-                               cap, H, W, max_dist, conn8, max_gap, dmax, cnt, (const long *)nullptr, (int *)nullptr,
-                               (short *)nullptr, (unsigned char *)nullptr, (const long *)nullptr, (long *)nullptr,
-                               (const short *)nullptr);
         }
+        if (grid && vis) launch(arcs_open_kernel<false, true, true>);
+        else if (grid) launch(arcs_open_kernel<false, true, false>);
+        else if (vis) launch(arcs_open_kernel<false, false, true>);
+        else launch(arcs_open_kernel<false, false, false>);
         AXT_LAUNCH_CHECK();
         hipLaunchKernelGGL(row_ptr_kernel, dim3(1), dim3(1024), 0, st, cnt, frame_off, n_frames, max_gap,
                            (long *)d_row_ptr);
@@ -289,17 +338,40 @@ int axt_build_arcs(const int32_t *d_x, const int32_t *d_y, const int32_t *d_coun
         return AXT_OK;
     }
     AXT_REQUIRE(d_len && d_gap, "null argument");
-    AXT_REQUIRE((d_cost == nullptr) == (d_cost_units == nullptr), "d_cost and d_cost_units go together");
-    if (grid)
-        hipLaunchKernelGGL((arcs_open_kernel<true, true>), grid_dim, block, 0, st, d_x, d_y, d_count, frame_off, n_frames, cap, H,
-                           W, max_dist, conn8, max_gap, dmax, cnt, (const long *)d_row_ptr, d_col, d_len, d_gap,
-                           (const long *)d_cost_units, (long *)d_cost, (const short *)Dtmp);
-    else
-        hipLaunchKernelGGL((arcs_open_kernel<true, false>), grid_dim, block, 0, st, d_x, d_y, d_count, frame_off, n_frames, cap,
-                           H, W, max_dist, conn8, max_gap, dmax, cnt, (const long *)d_row_ptr, d_col, d_len, d_gap,
-                           (const long *)d_cost_units, (long *)d_cost, (const short *)nullptr);
+    AXT_REQUIRE(vis || (d_cost == nullptr) == (d_cost_units == nullptr), "d_cost and d_cost_units go together");
+    if (grid && vis) launch(arcs_open_kernel<true, true, true>);
+    else if (grid) launch(arcs_open_kernel<true, true, false>);
+    else if (vis) launch(arcs_open_kernel<true, false, true>);
+    else launch(arcs_open_kernel<true, false, false>);
     AXT_LAUNCH_CHECK();
     return AXT_OK;
+}
+
+int axt_build_arcs(const int32_t *d_x, const int32_t *d_y, const int32_t *d_count, int n_frames, int cap,
+                   const axt_grid *grid, int H, int W, int max_dist, int conn8, int max_gap, const int32_t *h_dmax,
+                   int64_t *d_row_ptr, int32_t *d_work, int32_t *d_col, int16_t *d_len, uint8_t *d_gap,
+                   const int64_t *d_cost_units, int64_t *d_cost, int64_t *n_arcs, void *stream)
+{
+    return build_arcs_impl(d_x, d_y, d_count, n_frames, cap, grid, H, W, max_dist, conn8, max_gap, h_dmax, d_row_ptr, d_work,
+                           d_col, d_len, d_gap, d_cost_units, d_cost, n_arcs, nullptr, stream);
+}
+
+int axt_build_arcs_vis(const int32_t *d_x, const int32_t *d_y, const int32_t *d_count, int n_frames, int cap,
+                       const axt_grid *grid, int H, int W, int max_dist, int conn8, int max_gap, const int32_t *h_dmax,
+                       const float *d_hist, const double *d_hist_sum, double vis_weight, double miss_rate,
+                       double edge_cost_thr, int64_t *d_row_ptr, int32_t *d_work, int32_t *d_col, int16_t *d_len,
+                       uint8_t *d_gap, int64_t *d_cost, int64_t *n_arcs, void *stream)
+{
+    AXT_REQUIRE(d_hist && d_hist_sum, "axt_build_arcs_vis: null histogram argument");
+    AXT_REQUIRE(vis_weight > 0.0 && vis_weight <= 1.0, "axt_build_arcs_vis: weight %g outside (0,1]", vis_weight);
+    VisParams vp;
+    vp.hist = d_hist;
+    vp.hsum = d_hist_sum;
+    vp.w = vis_weight;
+    vp.thr = edge_cost_thr;
+    for (int g = 0; g < 8; ++g) vp.mp[g] = pow(miss_rate, (double)g);          // miss_rate ** (gap - 1), as Python computes it
+    return build_arcs_impl(d_x, d_y, d_count, n_frames, cap, grid, H, W, max_dist, conn8, max_gap, h_dmax, d_row_ptr, d_work,
+                           d_col, d_len, d_gap, nullptr, d_cost, n_arcs, &vp, stream);
 }
 
 }  // extern "C"

@@ -19,14 +19,14 @@ import torch
 from . import hotpath as hp
 
 
-def transition_cost_table(P, max_px=hp.MAX_PX_ASSOC_DIST):
+def transition_cost_table(P, max_px=hp.MAX_PX_ASSOC_DIST, vis_sim=0.0):
     """transition_model (mincostflow_models.py:67-119) tabulated for every integer path length
     D = 0..max_px and gap = 1..MCF_MAX_NUM_MISSES+1, numpy f64 exactly as the reference computes
-    it (vis_sim_weight must be 0: the visual term is a "next" row). Returns (cost f64
-    [gaps, max_px+1], dmax i32 [gaps]) with dmax = largest D whose cost < MCF_EDGE_COST_THR."""
+    it, for one value of the visual similarity. Returns (cost f64 [gaps, max_px+1], dmax i32 [gaps]) with
+    dmax = largest D whose cost < MCF_EDGE_COST_THR. With MCF_VIS_SIM_WEIGHT = 0 the table IS the cost model; with
+    a weight the costs are computed per pair on the GPU (axt_build_arcs_vis) and the table for vis_sim = 1 only
+    bounds the candidate pairs."""
     w = P['MCF_VIS_SIM_WEIGHT']
-    if w != 0:
-        raise NotImplementedError('MCF_VIS_SIM_WEIGHT > 0 (feature_model / compareHist) is not part of this build')
     gaps = P['MCF_MAX_NUM_MISSES'] + 1
     D = np.arange(0, max_px + 1)
     table = np.empty((gaps, max_px + 1))
@@ -34,7 +34,7 @@ def transition_cost_table(P, max_px=hp.MAX_PX_ASSOC_DIST):
     for g in range(1, gaps + 1):
         distances = ((D / max_px) - 1) * -1
         with np.errstate(divide='ignore'):
-            costs = -np.log((1 - w) * distances * (P['MCF_MISS_RATE'] ** (g - 1)) + w * 0.0 + 1e-6)
+            costs = -np.log((1 - w) * distances * (P['MCF_MISS_RATE'] ** (g - 1)) + w * vis_sim + 1e-6)
         costs[distances == 0] = np.inf
         table[g - 1] = costs
         ok = np.nonzero(costs[1:] < P['MCF_EDGE_COST_THR'])[0]
@@ -110,6 +110,15 @@ class AxonDetections(object):
         from .sharded import all_gather_detections
         import torch.distributed as dist
         local = int(self.d_count.shape[0])
+        if self.P['MCF_VIS_SIM_WEIGHT'] and dist.is_initialized() and dist.get_world_size(group) > 1:
+            # the appearance features need the pixels, which only the owning rank has: they travel with the detections
+            hist, hsum = self._appearance()
+            world = dist.get_world_size(group)
+            g_hist = torch.empty((world * local,) + tuple(hist.shape[1:]), dtype=hist.dtype, device=hist.device)
+            g_hsum = torch.empty((world * local, hsum.shape[1]), dtype=hsum.dtype, device=hsum.device)
+            dist.all_gather_into_tensor(g_hist, hist.contiguous(), group=group)
+            dist.all_gather_into_tensor(g_hsum, hsum.contiguous(), group=group)
+            self._hist = (g_hist, g_hsum)
         self.d_conf, self.d_x, self.d_y, self.d_count = all_gather_detections(
             self.d_conf, self.d_x, self.d_y, self.d_count, group)
         self._host, self._det_tables = None, None
@@ -259,6 +268,14 @@ class AxonDetections(object):
                 out[lbl] = D.cpu().numpy()
         return out
 
+    def _appearance(self):
+        """feature_model's histograms of every detection (device tensors hist f32 [F,cap,180], sums f64 [F,cap]),
+        computed once from the centre frames (AxonDetections.py:682-685)."""
+        if getattr(self, '_hist', None) is None:
+            self._hist = hp.box_histograms(self.dataset.frames, self.d_x, self.d_y, self.d_count, t_offset=2,
+                                           box=self.axon_box_size)
+        return self._hist
+
     def _mask_dev(self):
         """The timelapse's mask as a device grid handle (bit rows + connected components), built once."""
         m = self.dataset.mask2d
@@ -273,9 +290,12 @@ class AxonDetections(object):
         (parameters['ASSOCIATION'] = 'mcf', the default and the reference's behaviour) or by the
         frame-to-frame Hungarian variant of BASELINE config 3 ('hungarian')."""
         P = self.P
-        table, dmax = transition_cost_table(P, self.max_px_assoc_dist)
+        vis_w = P['MCF_VIS_SIM_WEIGHT']
+        table, dmax = transition_cost_table(P, self.max_px_assoc_dist, vis_sim=1.0 if vis_w else 0.0)
         units = np.where(np.isfinite(table), np.rint(table * 1e6), 0).astype(np.int64)
         mode = P.get('ASSOCIATION', 'mcf')
+        if vis_w and mode != 'mcf':
+            raise NotImplementedError("MCF_VIS_SIM_WEIGHT > 0 is implemented for ASSOCIATION='mcf' only")
         masked = self.dataset.mask2d is not None
         shard = getattr(self, '_shard', None)           # set by gather_detections(): solve only this rank's frame pairs
         if mode == 'hungarian':
@@ -292,9 +312,13 @@ class AxonDetections(object):
         if mode != 'mcf':
             raise ValueError(f"parameters['ASSOCIATION'] must be 'mcf' or 'hungarian', got {mode!r}")
         obs = hp.obs_costs(self.d_conf, self.d_count, P['MCF_CONF_CAPPING_METHOD'], P['MCF_MAX_CONF_COST'])
+        vis = None
+        if vis_w:
+            hist, hsum = self._appearance()
+            vis = dict(hist=hist, hsum=hsum, weight=vis_w, miss_rate=P['MCF_MISS_RATE'], thr=P['MCF_EDGE_COST_THR'])
         row_ptr, col, length, gap, cost = hp.build_arcs(self.d_x, self.d_y, self.d_count, self.dataset.sizey,
                                                         self.dataset.sizex, dmax, units, self._mask_dev(),
-                                                        self.max_px_assoc_dist, self.conn8)
+                                                        self.max_px_assoc_dist, self.conn8, vis)
         cnt, conf, x, y = self._host_dets()
         offs = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
         n_det = int(offs[-1])

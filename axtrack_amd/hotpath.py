@@ -222,9 +222,25 @@ def path_cost(xa, ya, xb, yb, H, W, mask=None, max_dist=MAX_PX_ASSOC_DIST, conn8
     return D
 
 
-def build_arcs(x, y, count, H, W, dmax, cost_units=None, mask=None, max_dist=MAX_PX_ASSOC_DIST, conn8=False):
+def box_histograms(frames, x, y, count, t_offset=2, box=AXON_BOX_SIZE):
+    """feature_model (mincostflow_models.py:30-65) for every detection: (hist f32 [F,cap,180], bin sums f64 [F,cap]).
+    frames f32 [T_all,H,W] on the GPU; detection frame f is shown frame f + t_offset (its centre frame)."""
+    n_frames, cap = x.shape
+    T_all, H, W = frames.shape
+    hist = torch.zeros((n_frames, cap, 180), dtype=torch.float32, device=x.device)
+    hsum = torch.zeros((n_frames, cap), dtype=torch.float64, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().axt_box_histograms(frames.data_ptr(), T_all, H, W, int(t_offset), x.data_ptr(), y.data_ptr(),
+                                                  count.data_ptr(), n_frames, cap, int(box), hist.data_ptr(),
+                                                  hsum.data_ptr(), _stream()), 'axt_box_histograms')
+    return hist, hsum
+
+
+def build_arcs(x, y, count, H, W, dmax, cost_units=None, mask=None, max_dist=MAX_PX_ASSOC_DIST, conn8=False, vis=None):
     """Admissible transition arcs of the whole timelapse, CSR by tail detection (global numbering).
     cost_units: optional int64 [max_gap, max_dist+1] = round(transition cost * 1e6) per (gap, D).
+    vis: None, or dict(hist, hsum, weight, miss_rate, thr) -- the appearance term (MCF_VIS_SIM_WEIGHT > 0): costs
+    are then computed per pair on the GPU and cost_units is ignored.
     Returns device tensors (row_ptr i64 [n_frames*cap+1], col i32, length i16, gap u8, cost i64|None)."""
     n_frames, cap = x.shape
     max_gap = len(dmax)
@@ -239,22 +255,35 @@ def build_arcs(x, y, count, H, W, dmax, cost_units=None, mask=None, max_dist=MAX
     work = torch.empty((n_work,), dtype=torch.int32, device=dev)
     n_arcs = ctypes.c_int64(0)
     lib = _lib.load()
-    args = (x.data_ptr(), y.data_ptr(), count.data_ptr(), n_frames, cap, mask._h if mask is not None else None, H, W, int(max_dist),
-            int(bool(conn8)), max_gap, h_dmax.ctypes.data, row_ptr.data_ptr(), work.data_ptr())
+    head = (x.data_ptr(), y.data_ptr(), count.data_ptr(), n_frames, cap, mask._h if mask is not None else None, H, W, int(max_dist),
+            int(bool(conn8)), max_gap, h_dmax.ctypes.data)
+    if vis is not None:
+        head += (vis['hist'].data_ptr(), vis['hsum'].data_ptr(), float(vis['weight']), float(vis['miss_rate']), float(vis['thr']))
+    head += (row_ptr.data_ptr(), work.data_ptr())
+
+    def call(col, length, gap, cu, cost, what):
+        if vis is None:
+            rc = lib.axt_build_arcs(*head, _lib.dptr(col), _lib.dptr(length), _lib.dptr(gap), _lib.dptr(cu), _lib.dptr(cost),
+                                    ctypes.byref(n_arcs), _stream())
+        else:
+            rc = lib.axt_build_arcs_vis(*head, _lib.dptr(col), _lib.dptr(length), _lib.dptr(gap), _lib.dptr(cost),
+                                        ctypes.byref(n_arcs), _stream())
+        _lib.check(rc, f'axt_build_arcs({what})')
+
     with torch.cuda.device(dev):
-        _lib.check(lib.axt_build_arcs(*args, None, None, None, None, None, ctypes.byref(n_arcs), _stream()),
-                   'axt_build_arcs(count)')
+        call(None, None, None, None, None, 'count')
         n = max(int(n_arcs.value), 1)
         col = torch.empty((n,), dtype=torch.int32, device=dev)
         length = torch.empty((n,), dtype=torch.int16, device=dev)
         gap = torch.empty((n,), dtype=torch.uint8, device=dev)
         cost = cu = None
-        if cost_units is not None:
+        if vis is not None:
+            cost = torch.empty((n,), dtype=torch.int64, device=dev)
+        elif cost_units is not None:
             cu = torch.as_tensor(np.ascontiguousarray(cost_units, np.int64)).to(dev)
             assert cu.shape == (max_gap, max_dist + 1)
             cost = torch.empty((n,), dtype=torch.int64, device=dev)
-        _lib.check(lib.axt_build_arcs(*args, col.data_ptr(), length.data_ptr(), gap.data_ptr(), _lib.dptr(cu),
-                                      _lib.dptr(cost), ctypes.byref(n_arcs), _stream()), 'axt_build_arcs(fill)')
+        call(col, length, gap, cu, cost, 'fill')
     n = int(n_arcs.value)
     return row_ptr, col[:n], length[:n], gap[:n], (cost[:n] if cost is not None else None)
 

@@ -174,6 +174,31 @@ int axt_build_arcs(const int32_t *d_x, const int32_t *d_y, const int32_t *d_coun
                    const int64_t *d_cost_units, int64_t *d_cost, int64_t *n_arcs, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Appearance term of the transition cost, MCF_VIS_SIM_WEIGHT > 0.
+ *
+ * axt_box_histograms = feature_model (axtrack/mincostflow_models.py:30-65): for every detection the
+ * 180-bin histogram on [0,1) of the box x box crop of frame (f + t_offset) of d_frames -- the centre frame
+ * of detection frame f, which is what the tracker is shown (AxonDetections.py:682-685) -- min-max
+ * normalised. The crop starts at (max(y - box/2, 0), max(x - box/2, 0)) and is clipped at the far edges.
+ * d_hist f32 [n_frames, cap, 180], d_hist_sum f64 [n_frames, cap] (bin sums, used by the distance).
+ *
+ * axt_build_arcs_vis = axt_build_arcs with the cost of transition_model (:100-118) computed per pair:
+ *   cost = -log((1-w) * (1 - D/max_dist) * miss_rate^(gap-1) + w * (1 - d_B(hist_a, hist_b)) + 1e-6)
+ * d_B = cv2.compareHist(.., HISTCMP_BHATTACHARYYA); an arc is kept iff cost < edge_cost_thr, and
+ * d_cost (may be NULL) receives round(cost * 1e6) << 16 | hash16(3, a, b). h_dmax[g-1] only bounds the
+ * candidates: pass the largest D whose cost with similarity 1 is still below the threshold. Same two
+ * phases and scratch as axt_build_arcs. cv2 is absent from the reference tree: parity unpinned.
+ * ------------------------------------------------------------------------------------------ */
+int axt_box_histograms(const float *d_frames, int T_all, int H, int W, int t_offset, const int32_t *d_x,
+                       const int32_t *d_y, const int32_t *d_count, int n_frames, int cap, int box,
+                       float *d_hist, double *d_hist_sum, void *stream);
+int axt_build_arcs_vis(const int32_t *d_x, const int32_t *d_y, const int32_t *d_count, int n_frames, int cap,
+                       const axt_grid *grid, int H, int W, int max_dist, int conn8, int max_gap, const int32_t *h_dmax,
+                       const float *d_hist, const double *d_hist_sum, double vis_weight, double miss_rate,
+                       double edge_cost_thr, int64_t *d_row_ptr, int32_t *d_work, int32_t *d_col, int16_t *d_len,
+                       uint8_t *d_gap, int64_t *d_cost, int64_t *n_arcs, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Global data association. Replaces libmot's MinCostFlowTracker as driven by
  * AxonDetections.py:663-690 (process() per frame, then compute_trajectories()).
  * HOST function (exact successive-shortest-path min-cost flow on the unit-capacity tracking

@@ -264,3 +264,64 @@ int orc_mcf_ssp(int n_nodes, int n_arcs, const int32_t *tail, const int32_t *hea
     free(dist); free(pred);
     return F;
 }
+
+/* ------------------------------------------------------------------------------------
+ * f-3: appearance features and their distance, mincostflow_models.py:30-65,107-113.
+ * The three cv2 calls the reference makes (cv2 4.5.1 is absent here: PARITY UNPINNED) are restated
+ * from OpenCV's published behaviour:
+ *   calcHist([crop],[0],None,[180],[0,1])       bin = floor((double)v * 180), counted iff 0 <= bin < 180
+ *                                               (v == 1.0 and everything outside [0,1) is dropped), f32 counts
+ *   normalize(h, h, 0, 1, NORM_MINMAX)          scale = 1/(max-min) if max-min > DBL_EPSILON else 0,
+ *                                               shift = -min*scale; h = (float)scale * h + (float)shift in f32
+ *   compareHist(f1, f2, HISTCMP_BHATTACHARYYA)  s12 = sum sqrt(a*b), s1 = sum a, s2 = sum b in double, in bin order;
+ *                                               s = s1*s2; s = |s| > FLT_EPSILON ? 1/sqrt(s) : 1;
+ *                                               d = sqrt(max(1 - s12*s, 0))
+ * The crop is feature_model's: rows [x1, x1+box) and columns [x2, x2+box) with x1 = max(y - box/2, 0),
+ * x2 = max(x - box/2, 0) (a box that starts outside the image is SHIFTED inside, not clipped), clipped by
+ * numpy slicing at the bottom / right edge.
+ * ------------------------------------------------------------------------------------ */
+void orc_box_histograms(const float *image, int H, int W, const int64_t *x, const int64_t *y, int n, int box,
+                        float *out /* [n,180] */)
+{
+    for (int k = 0; k < n; ++k) {
+        float h[180];
+        for (int i = 0; i < 180; ++i) h[i] = 0.f;
+        int64_t r0 = y[k] - box / 2, c0 = x[k] - box / 2;
+        if (r0 < 0) r0 = 0;
+        if (c0 < 0) c0 = 0;
+        int64_t r1 = r0 + box, c1 = c0 + box;
+        if (r1 > H) r1 = H;
+        if (c1 > W) c1 = W;
+        for (int64_t r = r0; r < r1; ++r)
+            for (int64_t c = c0; c < c1; ++c) {
+                const int idx = (int)floor((double)image[r * W + c] * 180.0);
+                if ((unsigned)idx < 180u) h[idx] += 1.f;
+            }
+        float mn = h[0], mx = h[0];
+        for (int i = 1; i < 180; ++i) { if (h[i] < mn) mn = h[i]; if (h[i] > mx) mx = h[i]; }
+        const double scale = ((double)mx - (double)mn > 2.220446049250313e-16) ? 1.0 / ((double)mx - (double)mn) : 0.0;
+        const float fs = (float)scale, fb = (float)(-(double)mn * scale);
+        for (int i = 0; i < 180; ++i) {
+            volatile float t = h[i] * fs;           /* f32 multiply, then f32 add: no fused multiply-add */
+            out[(size_t)k * 180 + i] = t + fb;
+        }
+    }
+}
+
+void orc_bhattacharyya(const float *h1, int n1, const float *h2, int n2, double *out /* [n1,n2] */)
+{
+    for (int i = 0; i < n1; ++i)
+        for (int j = 0; j < n2; ++j) {
+            double s12 = 0, s1 = 0, s2 = 0;
+            for (int b = 0; b < 180; ++b) {
+                const double a = h1[(size_t)i * 180 + b], c = h2[(size_t)j * 180 + b];
+                s12 += sqrt(a * c);
+                s1 += a;
+                s2 += c;
+            }
+            double s = s1 * s2;
+            s = fabs(s) > 1.1920928955078125e-07 ? 1.0 / sqrt(s) : 1.0;
+            const double d = 1.0 - s12 * s;
+            out[(size_t)i * n2 + j] = sqrt(d > 0 ? d : 0);
+        }
+}

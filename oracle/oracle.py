@@ -238,16 +238,38 @@ def observation_cost(scores, max_conf_cost=4.6):
     return s
 
 
-def transition_cost(D, gap, miss_rate=0.6, max_px=MAX_PX_ASSOC_DIST, vis_w=0):
-    """transition_model with vis_sim_weight = 0 (mincostflow_models.py:67-119), f64."""
-    assert vis_w == 0, 'visual similarity term is a "next" row (SURVEY.md 8f-3)'
+def transition_cost(D, gap, miss_rate=0.6, max_px=MAX_PX_ASSOC_DIST, vis_w=0, vis_sim=None):
+    """transition_model (mincostflow_models.py:67-119), f64. vis_sim: matrix of 1 - Bhattacharyya distance of
+    the appearance features (needed iff vis_w > 0; nan_to_num is a no-op on it, the distance is never nan)."""
     distances = ((np.asarray(D) / max_px) - 1) * -1
     inf = distances == 0
+    vs = 0.0 if vis_w == 0 else np.asarray(vis_sim, np.float64)
     with np.errstate(divide='ignore'):
-        costs = -np.log((1 - vis_w) * distances * (miss_rate ** (gap - 1)) + vis_w * 0.0 + 1e-6)
+        costs = -np.log((1 - vis_w) * distances * (miss_rate ** (gap - 1)) + vis_w * vs + 1e-6)
     costs = np.asarray(costs, np.float64)
     costs[inf] = np.inf
     return costs
+
+
+# ------------------------------------------------------------------------------- f-3 (next row)
+def box_histograms(image, x, y, box=AXON_BOX_SIZE):
+    """feature_model (mincostflow_models.py:30-65) for the libmot boxes (x - box//2, y - box//2, box, box) that
+    det2libmot_det builds (AxonDetections.py:754-784): f32 [n,180]. cv2 restated, PARITY UNPINNED (axt_oracle.c)."""
+    img = np.ascontiguousarray(image, np.float32)
+    xs, ys = np.ascontiguousarray(x, np.int64), np.ascontiguousarray(y, np.int64)
+    out = np.zeros((len(xs), 180), np.float32)
+    if len(xs):
+        lib().orc_box_histograms(_p(img), img.shape[0], img.shape[1], _p(xs), _p(ys), len(xs), int(box), _p(out))
+    return out
+
+
+def bhattacharyya(h1, h2):
+    """cv2.compareHist(f1, f2, HISTCMP_BHATTACHARYYA) for every pair (mincostflow_models.py:107-113): f64 [n1,n2]."""
+    a, b = np.ascontiguousarray(h1, np.float32), np.ascontiguousarray(h2, np.float32)
+    out = np.zeros((len(a), len(b)), np.float64)
+    if len(a) and len(b):
+        lib().orc_bhattacharyya(_p(a), len(a), _p(b), len(b), _p(out))
+    return out
 
 
 # ------------------------------------------------------------------------------- a-9
@@ -308,9 +330,11 @@ def arc_cost_int(cost, kind, a, b):
     return (int(np.rint(cost * COST_SCALE)) << PERT_BITS) + pert
 
 
-def build_flow_graph(dets, D, P=DEFAULTS, name='synth'):
+def build_flow_graph(dets, D, P=DEFAULTS, name='synth', images=None):
     """Arc lists of the tracking network the reference hands to libmot (call sites
-    AxonDetections.py:663-690): node 0 = source, 1 = sink, detection k -> (2+2k, 3+2k)."""
+    AxonDetections.py:663-690): node 0 = source, 1 = sink, detection k -> (2+2k, 3+2k).
+    images: per detection frame the image feature_model sees (the stitched centre frame, :682-685); needed iff
+    MCF_VIS_SIM_WEIGHT > 0."""
     counts = [len(d[0]) for d in dets]
     offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
     conf = np.concatenate([np.asarray(d[0], np.float32) for d in dets]).astype(np.float64) if sum(counts) else np.zeros(0)
@@ -318,6 +342,8 @@ def build_flow_graph(dets, D, P=DEFAULTS, name='synth'):
     obs = observation_cost(capped, P['MCF_MAX_CONF_COST']) if len(conf) else conf
     tail, head, cost = [], [], []
     ee = float(P['MCF_ENTRY_EXIT_COST'])
+    vis_w = P.get('MCF_VIS_SIM_WEIGHT', 0)
+    feats = [box_histograms(images[t], d[1], d[2]) for t, d in enumerate(dets)] if vis_w else None
     for k in range(int(offs[-1])):
         tail.append(0); head.append(2 + 2 * k); cost.append(arc_cost_int(ee, 0, k, 0))
         tail.append(2 + 2 * k); head.append(3 + 2 * k); cost.append(arc_cost_int(obs[k], 2, k, 0))
@@ -328,7 +354,8 @@ def build_flow_graph(dets, D, P=DEFAULTS, name='synth'):
             if tb < 0 or counts[t] == 0 or counts[tb] == 0:
                 continue
             Dm = D[f'{name}_t:{t:0>3}-t:{tb:0>3}']
-            c = transition_cost(Dm, gap, P['MCF_MISS_RATE'])
+            vs = 1 - bhattacharyya(feats[tb], feats[t]) if vis_w else None
+            c = transition_cost(Dm, gap, P['MCF_MISS_RATE'], vis_w=vis_w, vis_sim=vs)
             ii, jj = np.nonzero(c < P['MCF_EDGE_COST_THR'])
             for i, j in zip(ii, jj):
                 a, b = int(offs[tb] + i), int(offs[t] + j)
@@ -336,13 +363,13 @@ def build_flow_graph(dets, D, P=DEFAULTS, name='synth'):
     return (np.array(tail, np.int32), np.array(head, np.int32), np.array(cost, np.int64), offs)
 
 
-def mcf_solve(dets, D, P=DEFAULTS, name='synth'):
+def mcf_solve(dets, D, P=DEFAULTS, name='synth', images=None):
     """MinCostFlowTracker.process x frames + compute_trajectories (AxonDetections.py:679-690).
 
     Returns a list of trajectories, each a list of (frame, det_idx), or None if fewer than
     MCF_MIN_FLOW unit flows exist (the reference's falsy result, :691). Canonical order:
     by (first frame, det idx of the first detection)."""
-    tail, head, cost, offs = build_flow_graph(dets, D, P, name)
+    tail, head, cost, offs = build_flow_graph(dets, D, P, name, images)
     n_det = int(offs[-1])
     n_nodes = 2 + 2 * n_det
     flow = np.zeros(len(tail), np.uint8)
@@ -491,7 +518,8 @@ def inference(frames, sd, mask=None, P=DEFAULTS, name='synth', yolo=None, assoc=
         return dict(dets=dets, yolo=yolo, D=None, trajs=trajs, total_cost=None, tables=tables,
                     ided_all=ided_dets_all(tables))
     D = all_path_matrices(dets, frames.shape[1], frames.shape[2], mask, P['MCF_MAX_NUM_MISSES'], name)
-    trajs, total = mcf_solve(dets, D, P, name)
+    images = [frames[t + 2] for t in range(len(dets))] if P.get('MCF_VIS_SIM_WEIGHT', 0) else None   # the centre frames
+    trajs, total = mcf_solve(dets, D, P, name, images)
     tables = ided_tables(trajs, dets) if trajs else None
     return dict(dets=dets, yolo=yolo, D=D, trajs=trajs, total_cost=total, tables=tables,
                 ided_all=ided_dets_all(tables) if tables else None)

@@ -418,6 +418,84 @@ def test_two_rank_frame_sharding(weights):
         assert res[0][mode] == ref and res[1][mode] == ref, mode
 
 
+# ----------------------------------------------------------------------------------------- f-3 (next row)
+def test_box_histograms_bit_exact_against_oracle():
+    """feature_model on the GPU: boxes in the interior, on every edge and corner, partly and completely outside the
+    image, pixel values on both sides of the [0,1) histogram range and exactly on bin boundaries."""
+    rng = np.random.default_rng(5)
+    H, W, F, cap = 200, 260, 3, 16
+    frames = (rng.random((F + 4, H, W)) * 1.3).astype(np.float32)
+    frames[rng.random(frames.shape) < 0.6] = 0
+    frames[:, 50:60, 50:60] = np.float32(1.0)                       # == upper bound: dropped
+    frames[:, 60:70, 50:60] = (np.arange(10) / 180).astype(np.float32)[None, None, :]   # bin boundaries
+    x = rng.integers(-40, W + 40, (F, cap)).astype(np.int32)
+    y = rng.integers(-40, H + 40, (F, cap)).astype(np.int32)
+    x[0, :6] = [0, W - 1, 0, W - 1, 35, W + 100]
+    y[0, :6] = [0, 0, H - 1, H - 1, 35, H + 100]                    # corners, exact fit, far outside (empty crop)
+    cnt = np.array([cap, 9, 0], np.int32)
+    hist, hsum = hp.box_histograms(dev(frames), dev(x), dev(y), dev(cnt), t_offset=2)
+    hist, hsum = hist.cpu().numpy(), hsum.cpu().numpy()
+    for f in range(F):
+        n = int(cnt[f])
+        ref = orc.box_histograms(frames[f + 2], x[f, :n], y[f, :n])
+        assert np.array_equal(hist[f, :n].view(np.uint32), ref.view(np.uint32)), f
+        ref_sum = np.array([sum(float(v) for v in r) for r in ref])              # f64, in bin order
+        assert np.array_equal(hsum[f, :n], ref_sum), f
+        assert not hist[f, n:].any()
+
+
+def test_arcs_with_appearance_term_against_oracle(golden):
+    """MCF_VIS_SIM_WEIGHT = 0.3: candidate pairs up to D = 394, per-pair cost from the path length AND the Bhattacharyya
+    distance of the two crops, admission by cost < MCF_EDGE_COST_THR -- arcs and integer costs as the oracle's
+    restatement of transition_model (mincostflow_models.py:100-118)."""
+    from axtrack_amd.detections import transition_cost_table
+    g = golden('detect_1024')
+    dets = golden_dets(g)
+    F, cap = len(dets), 576
+    frames = synth.synth_frames(F + 4, 1024, 1024, seed=31) * np.float32(0.4)      # blobs inside the histogram range
+    x = np.zeros((F, cap), np.int32); y = np.zeros((F, cap), np.int32)
+    for t, d in enumerate(dets):
+        x[t, :len(d[1])] = d[1]; y[t, :len(d[2])] = d[2]
+    cnt = np.array([len(d[0]) for d in dets], np.int32)
+    P = dict(params.load_parameters(), MCF_VIS_SIM_WEIGHT=0.3)
+    _, dmax = transition_cost_table(P, vis_sim=1.0)
+    assert dmax[0] > 251                                                          # more candidates than without the term
+    hist, hsum = hp.box_histograms(dev(frames), dev(x), dev(y), dev(cnt), t_offset=2)
+    vis = dict(hist=hist, hsum=hsum, weight=0.3, miss_rate=P['MCF_MISS_RATE'], thr=P['MCF_EDGE_COST_THR'])
+    row_ptr, col, length, gap, cost = hp.build_arcs(dev(x), dev(y), dev(cnt), 1024, 1024, dmax, vis=vis)
+    row_ptr, col, cost = row_ptr.cpu().numpy(), col.cpu().numpy(), cost.cpu().numpy()
+    # oracle: the same arcs from its own flow-graph builder
+    Po = dict(orc.DEFAULTS, MCF_VIS_SIM_WEIGHT=0.3)
+    D = orc.all_path_matrices(dets, 1024, 1024)
+    tail, head, ocost, offs = orc.build_flow_graph(dets, D, Po, images=[frames[t + 2] for t in range(F)])
+    tr = (tail % 2 == 1) & (tail > 1) & (head > 1)                                 # transition arcs v_a -> u_b
+    ref = sorted(zip(((tail[tr] - 3) // 2).tolist(), ((head[tr] - 2) // 2).tolist(), ocost[tr].tolist()))
+    n_det = int(offs[-1])
+    got = sorted((a, int(col[e]), int(cost[e])) for a in range(n_det) for e in range(row_ptr[a], row_ptr[a + 1]))
+    assert len(got) == len(ref) > 1000
+    assert [r[:2] for r in got] == [r[:2] for r in ref]                            # the same arcs
+    du = np.array([(a[2] >> 16) - (b[2] >> 16) for a, b in zip(got, ref)])
+    assert np.abs(du).max() <= 1 and (du != 0).mean() < 1e-3                       # f64 log: 1 ulp on the GPU
+    assert all((a[2] & 0xFFFF) == (b[2] & 0xFFFF) for a, b in zip(got, ref))       # identity hash bits
+
+
+def test_inference_with_appearance_term(weights):
+    """End to end with MCF_VIS_SIM_WEIGHT = 0.2 (the reference's search grid uses 0.1 / 0.4, experiment.py:227):
+    same trajectories and IDed_dets_all as the oracle fed with the same YOLO grids."""
+    frames = synth.synth_frames(12, 1024, 1024, seed=13) * np.float32(0.5)
+    P = dict(params.load_parameters(), MCF_VIS_SIM_WEIGHT=0.2)
+    ad = _run_inference(frames, weights, P)
+    ref = orc.inference(frames, weights, P=dict(orc.DEFAULTS, MCF_VIS_SIM_WEIGHT=0.2), yolo=list(ad._yolo.cpu().numpy()))
+    assert ad.n_ids == len(ref['trajs'])
+    got_tracks = tracks_from_next(np.zeros(len(ad._track_flat)), ad._track_flat, ad._offs)
+    assert got_tracks == ref['trajs']
+    assert abs(ad.mcf_total_cost - ref['total_cost']) <= 65536 * 4                 # a few cost units (f64 log, 1 ulp)
+    assert np.array_equal(np.nan_to_num(ad.IDed_dets_all.to_numpy(), nan=-1), np.nan_to_num(ref['ided_all'][3], nan=-1))
+    # and it is a different problem from the one without the term
+    ad0 = _run_inference(frames, weights, params.load_parameters())
+    assert ad0.mcf_total_cost != ad.mcf_total_cost
+
+
 # ----------------------------------------------------------------------------------------- f-1 (next row)
 def test_preprocess_fused_pass_matches_oracle():
     rng = np.random.default_rng(3)
