@@ -126,3 +126,34 @@ def test_ided_dets_all_with_empty_frame_quirk(golden):
     assert np.array_equal(labels, a['ided_all_cols_frame'])
     assert list(info) == list(a['ided_all_cols_info'])
     np.testing.assert_array_equal(vals, a['ided_all_values'])
+
+
+def test_appearance_features_restatement_is_self_consistent():
+    """f-3: the C restatement of calcHist/normalize/compareHist against an independent numpy formulation of the same
+    published behaviour (cv2 is absent: this pins the oracle to its own specification, not to OpenCV)."""
+    rng = np.random.default_rng(12)
+    img = (rng.random((120, 150)) * 1.25).astype(np.float32)
+    img[rng.random(img.shape) < 0.5] = 0
+    x = np.array([0, 149, 75, -20, 200, 35]); y = np.array([0, 119, 60, 130, 50, 35])
+    h = orc.box_histograms(img, x, y)
+    for k in range(len(x)):
+        r0, c0 = max(int(y[k]) - 35, 0), max(int(x[k]) - 35, 0)
+        crop = img[r0:r0 + 70, c0:c0 + 70]
+        idx = np.floor(crop.astype(np.float64) * 180.0).astype(np.int64)
+        cnt = np.bincount(idx[(idx >= 0) & (idx < 180)], minlength=180).astype(np.float32)
+        rg = float(cnt.max()) - float(cnt.min())
+        sc = 1.0 / rg if rg > np.finfo(np.float64).eps else 0.0
+        ref = cnt * np.float32(sc) + np.float32(-float(cnt.min()) * sc)
+        assert np.array_equal(h[k], ref), k
+    assert not h[4].any()                                   # box entirely right of the image: empty crop
+    d = orc.bhattacharyya(h, h)
+    assert np.all(np.diag(d)[[0, 1, 2, 3, 5]] < 1e-7) and np.allclose(d, d.T, atol=1e-15)
+    a, b = h[0].astype(np.float64), h[2].astype(np.float64)
+    ref = np.sqrt(max(1 - np.sqrt(a * b).sum() / np.sqrt(a.sum() * b.sum()), 0))
+    assert abs(d[0, 2] - ref) < 1e-12
+    # the transition cost with the term: monotone in the similarity, equal to the table model at weight 0
+    D = np.array([[10, 200, 400]])
+    c0 = orc.transition_cost(D, 1)
+    c1 = orc.transition_cost(D, 1, vis_w=0.3, vis_sim=np.array([[1.0, 1.0, 1.0]]))
+    c2 = orc.transition_cost(D, 1, vis_w=0.3, vis_sim=np.array([[0.0, 0.0, 0.0]]))
+    assert np.all(c1 < c2) and np.all(c1[0, 1:] < c0[0, 1:])
