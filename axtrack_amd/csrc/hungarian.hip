@@ -39,22 +39,43 @@ __device__ __forceinline__ int h_path_len_open(int xa, int ya, int xb, int yb, i
     return (d2 < (long)max_dist * max_dist && len <= max_dist && inb) ? len : max_dist;
 }
 
-// wave-wide argmin of (key, idx): smallest key, ties to the smallest idx
+// wave-wide argmin of (key, idx): smallest key, ties to the smallest idx. Key (< 2^52) and index (< 2^11) travel as
+// one 64-bit word; inside each row of 16 lanes the minimum is formed with DPP moves (quad swaps, half-row and row
+// mirrors: 2-cycle VALU operations instead of ~100-cycle LDS-crossbar shuffles), the four row minima meet through
+// v_readlane.
+__device__ __forceinline__ unsigned long dpp_min_step(unsigned long v, unsigned long o) { return o < v ? o : v; }
+#define AXT_DPP_MIN(v, ctrl)                                                                              \
+    {                                                                                                     \
+        const unsigned lo_ = (unsigned)(v), hi_ = (unsigned)((v) >> 32);                                  \
+        const unsigned ol_ = __builtin_amdgcn_update_dpp(lo_, lo_, ctrl, 0xF, 0xF, false);                \
+        const unsigned oh_ = __builtin_amdgcn_update_dpp(hi_, hi_, ctrl, 0xF, 0xF, false);                \
+        (v) = dpp_min_step(v, ((unsigned long)oh_ << 32) | ol_);                                          \
+    }
 __device__ __forceinline__ void wave_argmin(long &key, int &idx)
 {
+    unsigned long v = key >= (1l << 51) ? ~0ul : (((unsigned long)key << 11) | (unsigned)idx);   // keys are >= 0
+    AXT_DPP_MIN(v, 0xB1);        // quad_perm [1,0,3,2]
+    AXT_DPP_MIN(v, 0x4E);        // quad_perm [2,3,0,1]
+    AXT_DPP_MIN(v, 0x141);       // row_half_mirror
+    AXT_DPP_MIN(v, 0x140);       // row_mirror: every lane of a row now holds the row's minimum
+    unsigned long best = ~0ul;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const long k2 = __shfl_xor(key, o);
-        const int i2 = __shfl_xor(idx, o);
-        if (k2 < key || (k2 == key && i2 < idx)) { key = k2; idx = i2; }
+    for (int r = 0; r < 4; ++r) {
+        const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, r * 16), hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), r * 16);
+        best = dpp_min_step(best, ((unsigned long)hi << 32) | lo);
     }
+    if (best == ~0ul) { key = HINF; idx = 0x7fffffff; }
+    else { key = (long)(best >> 11); idx = (int)(best & 2047u); }
 }
 
 // One wave per frame pair (t, t+gap). succ/pred are per detection slot [n_frames*cap]:
 //   GAP == 1: writes succ1[t*cap+i] = j or -1 and pred1[(t+1)*cap+j] = i or -1 for every slot of the pair.
 //   GAP == 2: rows = detections of t with succ1 < 0, columns = detections of t+2 with pred1 < 0;
 //             writes succ2 / pred2 the same way.
-template <int GAP>
+// NC > 0: frames with at most 64*NC detections -- the per-column search state (dual, distance, predecessor, matched
+// row, flags) lives in NC registers per lane instead of LDS, so that one search step costs one LDS round trip (the
+// cost row and the row dual) instead of a dozen dependent ones. NC == 0: any cap, column state in LDS.
+template <int GAP, int NC>
 __global__ __launch_bounds__(64) void hungarian_pair_kernel(
     const int *__restrict__ x, const int *__restrict__ y, const int *__restrict__ count,
     const int *__restrict__ frame_off, int n_frames, int cap, int H, int W, int max_dist, int conn8,
@@ -133,63 +154,153 @@ __global__ __launch_bounds__(64) void hungarian_pair_kernel(
     }
     __syncthreads();
 
-    for (int i = 0; i < n; ++i) {
-        if (GAP == 2 && succ1[(long)t * cap + i] >= 0) continue;      // wave-uniform
-        if (col4row[i] != -1) continue;                               // settled by the initialisation
-        for (int j = lane; j < m; j += 64) { spc[j] = HINF; in_sc[j] = 0; }
-        __syncthreads();
-        long minVal = 0, best_dummy = HINF;
-        int cur = i, dummy_row = -1, n_sr = 0, sink = -1;             // sink >= 0: real column; -2: dummy of dummy_row
-        for (;;) {
-            if (lane == 0) sr[n_sr] = cur;
-            ++n_sr;
-            const long ucur = u[cur];
-            const long rd = minVal + h_arc_cost_int(thr_units, 1, a0 + cur, 0) - ucur;
-            if (rd < best_dummy) { best_dummy = rd; dummy_row = cur; }
-            long bkey = HINF;
-            int bidx = 0x7fffffff;
-            for (int j = lane; j < m; j += 64) {
-                if (in_sc[j] || !col_ok[j]) continue;
-                const long c = cached ? ccache[cur * cdim + j] : link_cost(cur, j);
-                long s = spc[j];
-                if (c != HINF) {
-                    const long r = minVal + c - ucur - v[j];
-                    if (r < s) { s = r; spc[j] = r; pred[j] = cur; }
-                }
-                if (s < bkey) { bkey = s; bidx = j; }
-            }
-            wave_argmin(bkey, bidx);
-            if (best_dummy <= bkey) { sink = -2; minVal = best_dummy; break; }
-            minVal = bkey;
-            if (lane == 0) in_sc[bidx] = 1;
-            __syncthreads();
-            if (row4col[bidx] < 0) { sink = bidx; break; }
-            cur = row4col[bidx];
+    if constexpr (NC > 0) {
+        // ---- register-resident column state: column j = lane + 64*k lives in slot k of lane j % 64
+        constexpr int NS = NC > 0 ? NC : 1;
+        long v_r[NS], spc_r[NS];
+        int pred_r[NS], rc_r[NS];            // predecessor row in the search / matched row
+        bool ok_r[NS], sc_r[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int j = lane + 64 * k;
+            v_r[k] = 0;
+            ok_r[k] = j < m && col_ok[j];
+            rc_r[k] = j < m ? row4col[j] : -1;
         }
-        __syncthreads();
-        // dual update (Crouse 2016, Alg. 1): rows of SR, columns of SC
-        for (int k = lane; k < n_sr; k += 64) {
-            const int r = sr[k];
-            u[r] += (k == 0) ? minVal : minVal - spc[col4row[r]];
-        }
-        for (int j = lane; j < m; j += 64)
-            if (in_sc[j] && j != sink) v[j] -= minVal - spc[j];
-        __syncthreads();
-        // augment back to row i
-        if (lane == 0) {
-            int r, jnew;
-            if (sink == -2) { r = dummy_row; jnew = -2; }
-            else { r = pred[sink]; jnew = sink; }
+        for (int i = 0; i < n; ++i) {
+            if (GAP == 2 && succ1[(long)t * cap + i] >= 0) continue;      // wave-uniform
+            if (col4row[i] != -1) continue;                               // settled by the initialisation
+#pragma unroll
+            for (int k = 0; k < NS; ++k) { spc_r[k] = HINF; sc_r[k] = false; pred_r[k] = -1; }
+            long minVal = 0, best_dummy = HINF;
+            int cur = i, dummy_row = -1, n_sr = 0, sink = -1;             // sink >= 0: real column; -2: dummy of dummy_row
             for (;;) {
-                const int jprev = col4row[r];
-                col4row[r] = jnew;
-                if (jnew >= 0) row4col[jnew] = r;
-                if (r == i) break;
-                jnew = jprev;
-                r = pred[jnew];
+                if (lane == 0) sr[n_sr] = cur;
+                ++n_sr;
+                const long ucur = u[cur];
+                const long rd = minVal + h_arc_cost_int(thr_units, 1, a0 + cur, 0) - ucur;
+                if (rd < best_dummy) { best_dummy = rd; dummy_row = cur; }
+                long bkey = HINF;
+                int bidx = 0x7fffffff;
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    const int j = lane + 64 * k;
+                    if (sc_r[k] || !ok_r[k]) continue;
+                    const long c = cached ? ccache[cur * cdim + j] : link_cost(cur, j);
+                    if (c != HINF) {
+                        const long r = minVal + c - ucur - v_r[k];
+                        if (r < spc_r[k]) { spc_r[k] = r; pred_r[k] = cur; }
+                    }
+                    if (spc_r[k] < bkey) { bkey = spc_r[k]; bidx = j; }
+                }
+                wave_argmin(bkey, bidx);
+                if (best_dummy <= bkey) { sink = -2; minVal = best_dummy; break; }
+                minVal = bkey;
+                // the winning column (wave-uniform index) joins the tree; its owner tells everyone the matched row
+                int matched = -1;
+#pragma unroll
+                for (int k = 0; k < NS; ++k)
+                    if ((bidx >> 6) == k) {
+                        if (lane == (bidx & 63)) sc_r[k] = true;
+                        matched = __builtin_amdgcn_readlane(rc_r[k], bidx & 63);
+                    }
+                if (matched < 0) { sink = bidx; break; }
+                cur = matched;
+            }
+            // publish what the row update and the augmentation read: distances and predecessors of the tree's columns
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int j = lane + 64 * k;
+                if (j < m && sc_r[k]) { spc[j] = spc_r[k]; pred[j] = pred_r[k]; }
+                if (j < m && sc_r[k] && j != sink) v_r[k] -= minVal - spc_r[k];      // dual update of the columns
+            }
+            __syncthreads();
+            // dual update (Crouse 2016, Alg. 1): rows of SR
+            for (int k = lane; k < n_sr; k += 64) {
+                const int r = sr[k];
+                u[r] += (k == 0) ? minVal : minVal - spc[col4row[r]];
+            }
+            __syncthreads();
+            // augment back to row i
+            if (lane == 0) {
+                int r, jnew;
+                if (sink == -2) { r = dummy_row; jnew = -2; }
+                else { r = pred[sink]; jnew = sink; }
+                for (;;) {
+                    const int jprev = col4row[r];
+                    col4row[r] = jnew;
+                    if (jnew >= 0) row4col[jnew] = r;
+                    if (r == i) break;
+                    jnew = jprev;
+                    r = pred[jnew];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int j = lane + 64 * k;
+                if (j < m) rc_r[k] = row4col[j];
             }
         }
-        __syncthreads();
+    } else {
+    for (int i = 0; i < n; ++i) {
+            if (GAP == 2 && succ1[(long)t * cap + i] >= 0) continue;      // wave-uniform
+            if (col4row[i] != -1) continue;                               // settled by the initialisation
+            for (int j = lane; j < m; j += 64) { spc[j] = HINF; in_sc[j] = 0; }
+            __syncthreads();
+            long minVal = 0, best_dummy = HINF;
+            int cur = i, dummy_row = -1, n_sr = 0, sink = -1;             // sink >= 0: real column; -2: dummy of dummy_row
+            for (;;) {
+                if (lane == 0) sr[n_sr] = cur;
+                ++n_sr;
+                const long ucur = u[cur];
+                const long rd = minVal + h_arc_cost_int(thr_units, 1, a0 + cur, 0) - ucur;
+                if (rd < best_dummy) { best_dummy = rd; dummy_row = cur; }
+                long bkey = HINF;
+                int bidx = 0x7fffffff;
+                for (int j = lane; j < m; j += 64) {
+                    if (in_sc[j] || !col_ok[j]) continue;
+                    const long c = cached ? ccache[cur * cdim + j] : link_cost(cur, j);
+                    long s = spc[j];
+                    if (c != HINF) {
+                        const long r = minVal + c - ucur - v[j];
+                        if (r < s) { s = r; spc[j] = r; pred[j] = cur; }
+                    }
+                    if (s < bkey) { bkey = s; bidx = j; }
+                }
+                wave_argmin(bkey, bidx);
+                if (best_dummy <= bkey) { sink = -2; minVal = best_dummy; break; }
+                minVal = bkey;
+                if (lane == 0) in_sc[bidx] = 1;
+                __syncthreads();
+                if (row4col[bidx] < 0) { sink = bidx; break; }
+                cur = row4col[bidx];
+            }
+            __syncthreads();
+            // dual update (Crouse 2016, Alg. 1): rows of SR, columns of SC
+            for (int k = lane; k < n_sr; k += 64) {
+                const int r = sr[k];
+                u[r] += (k == 0) ? minVal : minVal - spc[col4row[r]];
+            }
+            for (int j = lane; j < m; j += 64)
+                if (in_sc[j] && j != sink) v[j] -= minVal - spc[j];
+            __syncthreads();
+            // augment back to row i
+            if (lane == 0) {
+                int r, jnew;
+                if (sink == -2) { r = dummy_row; jnew = -2; }
+                else { r = pred[sink]; jnew = sink; }
+                for (;;) {
+                    const int jprev = col4row[r];
+                    col4row[r] = jnew;
+                    if (jnew >= 0) row4col[jnew] = r;
+                    if (r == i) break;
+                    jnew = jprev;
+                    r = pred[jnew];
+                }
+            }
+            __syncthreads();
+        }
     }
     for (int i = lane; i < n; i += 64) {
         const bool active = (GAP == 1) || (succ1[(long)t * cap + i] < 0);
@@ -302,21 +413,23 @@ extern "C" int axt_hungarian_pairs(const int32_t *d_x, const int32_t *d_y, const
     const size_t lds = lds_base + (size_t)cdim * cdim * 8;
     static bool attr = false;
     if (!attr) {
-        AXT_CHECK_HIP(hipFuncSetAttribute((const void *)hungarian_pair_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        AXT_CHECK_HIP(hipFuncSetAttribute((const void *)hungarian_pair_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        AXT_CHECK_HIP(hipFuncSetAttribute((const void *)hungarian_pair_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        AXT_CHECK_HIP(hipFuncSetAttribute((const void *)hungarian_pair_kernel<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        AXT_CHECK_HIP(hipFuncSetAttribute((const void *)hungarian_pair_kernel<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        AXT_CHECK_HIP(hipFuncSetAttribute((const void *)hungarian_pair_kernel<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
     // pass 2 of source frame t needs pass 1 of the pairs (t, t+1) and (t+1, t+2): pass 1 runs one frame further
     const int e1 = (max_gap == 2 ? t_end + 1 : t_end) < n_frames - 1 ? (max_gap == 2 ? t_end + 1 : t_end) : n_frames - 1;
     if (e1 > t_begin) {
-        hipLaunchKernelGGL(hungarian_pair_kernel<1>, dim3(e1 - t_begin), dim3(64), lds, st, d_x, d_y, d_count, frame_off,
+        hipLaunchKernelGGL((cap <= 192 ? hungarian_pair_kernel<1, 3> : hungarian_pair_kernel<1, 0>), dim3(e1 - t_begin), dim3(64), lds, st, d_x, d_y, d_count, frame_off,
                            n_frames, cap, H, W, max_dist, conn8, h_dmax[0], (const long *)d_cost_units, (long)thr_units,
                            (const int *)nullptr, (const int *)nullptr, succ1, pred1, cdim, t_begin);
         AXT_LAUNCH_CHECK();
     }
     const int e2 = t_end < n_frames - 2 ? t_end : n_frames - 2;
     if (max_gap == 2 && e2 > t_begin) {
-        hipLaunchKernelGGL(hungarian_pair_kernel<2>, dim3(e2 - t_begin), dim3(64), lds, st, d_x, d_y, d_count, frame_off,
+        hipLaunchKernelGGL((cap <= 192 ? hungarian_pair_kernel<2, 3> : hungarian_pair_kernel<2, 0>), dim3(e2 - t_begin), dim3(64), lds, st, d_x, d_y, d_count, frame_off,
                            n_frames, cap, H, W, max_dist, conn8, h_dmax[1],
                            (const long *)d_cost_units + (max_dist + 1), (long)thr_units, (const int *)succ1,
                            (const int *)pred1, succ2, pred2, cdim, t_begin);
