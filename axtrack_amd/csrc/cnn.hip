@@ -660,6 +660,7 @@ struct axt_detector {
     size_t bytes = 0;
     // optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg)
     bool profiling = false;
+    int profile_only = -1;      // >= 0: only this kernel index is bracketed with events
     struct Span { hipEvent_t a, b; int kernel; int items; };
     std::vector<Span> spans;
     std::vector<hipEvent_t> free_events;
@@ -687,7 +688,7 @@ struct ProfSpan {
     int kernel, items;
     ProfSpan(axt_detector *d_, hipStream_t st_, int kernel_, int items_) : d(d_), st(st_), kernel(kernel_), items(items_)
     {
-        if (!d->profiling) return;
+        if (!d->profiling || (d->profile_only >= 0 && d->profile_only != kernel_)) return;
         a = take_event(d);
         b = take_event(d);
         (void)hipEventRecord(a, st);
@@ -1061,6 +1062,7 @@ int axt_detector_set_profiling(axt_detector *d, int on)
 {
     AXT_REQUIRE(d, "null argument");
     d->profiling = on != 0;
+    d->profile_only = on >= 2 ? on - 2 : -1;
     return AXT_OK;
 }
 

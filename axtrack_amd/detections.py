@@ -291,8 +291,7 @@ class AxonDetections(object):
         frame-to-frame Hungarian variant of BASELINE config 3 ('hungarian')."""
         P = self.P
         vis_w = P['MCF_VIS_SIM_WEIGHT']
-        table, dmax = transition_cost_table(P, self.max_px_assoc_dist, vis_sim=1.0 if vis_w else 0.0)
-        units = np.where(np.isfinite(table), np.rint(table * 1e6), 0).astype(np.int64)
+        dmax, units = _cost_units_on_device(P, self.max_px_assoc_dist, self.device)
         mode = P.get('ASSOCIATION', 'mcf')
         if vis_w and mode != 'mcf':
             raise NotImplementedError("MCF_VIS_SIM_WEIGHT > 0 is implemented for ASSOCIATION='mcf' only")
@@ -401,6 +400,19 @@ class AxonDetections(object):
 
 
 _COLUMNS_CACHE = {}
+_UNITS_CACHE = {}
+
+
+def _cost_units_on_device(P, max_px, device):
+    """(dmax i32 [gaps], integer cost table i64 [gaps, max_px+1] on `device`) of the transition model for these
+    parameters. Cached: the table is a pure function of four parameters, and uploading it from pageable memory in
+    the middle of a pass would make the host wait for the detector."""
+    key = (P['MCF_VIS_SIM_WEIGHT'], P['MCF_MAX_NUM_MISSES'], P['MCF_MISS_RATE'], P['MCF_EDGE_COST_THR'], max_px, str(device))
+    if key not in _UNITS_CACHE:
+        table, dmax = transition_cost_table(P, max_px, vis_sim=1.0 if P['MCF_VIS_SIM_WEIGHT'] else 0.0)
+        units = np.where(np.isfinite(table), np.rint(table * 1e6), 0).astype(np.int64)
+        _UNITS_CACHE[key] = (dmax, torch.from_numpy(units).to(device))
+    return _UNITS_CACHE[key]
 
 
 def _ided_columns(F):

@@ -73,8 +73,10 @@ class Detector:
                     'conv7 80>80', 'conv8 80>80 +pool', 'conv10 80>160', 'fc1 gemm', 'fc1 reduce', 'fc2 gemm',
                     'fc2 reduce', 'fc3 gemm', 'fc3 reduce']
 
-    def set_profiling(self, on):
-        _lib.check(self._lib.axt_detector_set_profiling(self._h, int(bool(on))), 'axt_detector_set_profiling')
+    def set_profiling(self, on, only=None):
+        """Bracket the forward pass's kernel launches with HIP events: all of them, or only kernel index `only`."""
+        mode = 0 if not on else (1 if only is None else 2 + int(only))
+        _lib.check(self._lib.axt_detector_set_profiling(self._h, mode), 'axt_detector_set_profiling')
 
     def read_profile(self):
         """Per-kernel HIP-event times since the last read: list of dicts (name, ms, launches, tiles, flops_per_tile)."""
@@ -280,7 +282,7 @@ def build_arcs(x, y, count, H, W, dmax, cost_units=None, mask=None, max_dist=MAX
         if vis is not None:
             cost = torch.empty((n,), dtype=torch.int64, device=dev)
         elif cost_units is not None:
-            cu = torch.as_tensor(np.ascontiguousarray(cost_units, np.int64)).to(dev)
+            cu = cost_units if isinstance(cost_units, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(cost_units, np.int64)).to(dev)
             assert cu.shape == (max_gap, max_dist + 1)
             cost = torch.empty((n,), dtype=torch.int64, device=dev)
         call(col, length, gap, cu, cost, 'fill')
@@ -298,7 +300,7 @@ def hungarian_assoc(x, y, count, H, W, dmax, cost_units, thr_units, max_dist=MAX
     max_gap = len(dmax)
     dev = x.device
     h_dmax = np.ascontiguousarray(dmax, np.int32)
-    cu = torch.as_tensor(np.ascontiguousarray(cost_units, np.int64)).to(dev)
+    cu = cost_units if isinstance(cost_units, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(cost_units, np.int64)).to(dev)
     slots = n_frames * cap
     pred = torch.empty((2 * slots,), dtype=torch.int32, device=dev)
     work = torch.empty((2 * slots + n_frames + 1,), dtype=torch.int32, device=dev)

@@ -105,8 +105,18 @@ def main():
     for _ in range(args.warmup):
         ad = step()
     sync_all()
+    # Per-kernel table: one extra untimed pass with every launch bracketed by HIP events (that costs ~8 % of the
+    # pass, so it stays outside the timed region). Inside the timed region only the dominant kernel is bracketed:
+    # its time there is what roofline.achieved is computed from.
+    table, dom_idx = None, None
     if not args.no_profile:
         model.set_profiling(True)
+        model.read_profile()
+        step()
+        sync_all()
+        table = model.read_profile()
+        dom_idx = max(range(len(table)), key=lambda i: table[i]['ms'])
+        model.set_profiling(True, only=dom_idx)
         model.read_profile()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -174,22 +184,24 @@ def main():
             if other:
                 out['other_association_variant'] = other
         if prof:
-            dom = max(prof, key=lambda k: k['ms'])
+            dom = prof[dom_idx]                                   # bracketed inside the timed region
             flops = dom['flops_per_tile'] * dom['tiles']
             achieved = flops / (dom['ms'] * 1e-3) / 1e12
-            cnn_ms = sum(k['ms'] for k in prof)
-            cnn_flops = sum(k['flops_per_tile'] * k['tiles'] for k in prof if 'reduce' not in k['name'])
+            cnn_ms = sum(k['ms'] for k in table)                  # one untimed pass, all launches bracketed
+            cnn_flops = sum(k['flops_per_tile'] * k['tiles'] for k in table if 'reduce' not in k['name'])
             out['roofline'] = {
                 'bound': 'mfma', 'kernel': dom['name'], 'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
                 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': committed_traffic(dom['name']),
                 'avg_launch_ms': round(dom['ms'] / max(dom['launches'], 1), 4),
                 'flops_per_launch': flops / max(dom['launches'], 1),
+                'measured': 'HIP events around every launch of this kernel inside the timed region',
                 'whole_cnn': {'achieved': round(cnn_flops / (cnn_ms * 1e-3) / 1e12, 2),
                               'frac': round(cnn_flops / (cnn_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                              'ms_per_step': round(cnn_ms / args.steps, 3)},
-                'kernels': [{'name': k['name'], 'ms_per_step': round(k['ms'] / args.steps, 4),
+                              'ms_per_step': round(cnn_ms, 3),
+                              'measured': 'one untimed pass with every launch bracketed'},
+                'kernels': [{'name': k['name'], 'ms_per_step': round(k['ms'], 4),
                              'tflops': round(k['flops_per_tile'] * k['tiles'] / max(k['ms'], 1e-9) / 1e9, 2)}
-                            for k in prof],
+                            for k in table],
             }
         if world == 1 and args.cpu_frames > 0:
             out['cpu_baseline'] = cpu_baseline(args, sd, synth)

@@ -81,8 +81,10 @@ int axt_cnn_forward_frames(axt_detector *det, const float *d_frames, int T_all, 
 /* FLOPs of one tile-forward (algorithmic: 2*M*N*K of the unpadded layers). */
 double axt_cnn_flops_per_tile(void);
 
-/* Per-kernel timing for the roofline report (bench.py): when on, every kernel launch of the
- * forward pass is bracketed by HIP events on the launch stream. Kernel ids: 0..7 the eight conv
+/* Per-kernel timing for the roofline report (bench.py): on = 1, every kernel launch of the
+ * forward pass is bracketed by HIP events on the launch stream; on = 2 + k, only the launches of
+ * kernel id k are (two events per launch cost ~10 us of launch gap: bracketing all 19 launches of a
+ * pass slows it by ~8 %, bracketing the dominant kernel alone by < 1 %); on = 0, none. Kernel ids: 0..7 the eight conv
  * blocks, 8/10/12 the linear-layer GEMMs, 9/11/13 their split-K reductions.
  * axt_detector_read_profile synchronises on the recorded events and returns, per kernel id, the
  * summed milliseconds, the number of launches and the number of tile-forwards since the last read. */
