@@ -335,33 +335,27 @@ __global__ void chain_jump_kernel(const int *__restrict__ in, int *__restrict__ 
     out[s] = (r < 0) ? -1 : in[r];
 }
 
-// ids of roots = exclusive prefix count of (root[s] == s) in slot order; single block, chunked scan
+// ids of roots = exclusive prefix count of (root[s] == s) in slot order. Single block: every thread counts the roots
+// of one contiguous run of slots, the 1024 counts are scanned in LDS, then the thread numbers its roots.
 __global__ __launch_bounds__(1024) void chain_rank_kernel(const int *__restrict__ root, long n, int *__restrict__ rank,
                                                           int *__restrict__ n_tracks)
 {
-    __shared__ int wtot[16];
-    __shared__ int base;
-    if (threadIdx.x == 0) base = 0;
+    __shared__ int cnt[1024];
+    const long per = (n + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+    int c = 0;
+    for (long s = lo; s < hi; ++s) c += root[s] == (int)s;
+    cnt[threadIdx.x] = c;
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (long s0 = 0; s0 < n; s0 += 1024) {
-        const long s = s0 + threadIdx.x;
-        const bool is_root = s < n && root[s] == (int)s;
-        const unsigned long long mk = __ballot(is_root);
-        if (lane == 0) wtot[wave] = __popcll(mk);
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int t = threadIdx.x >= o ? cnt[threadIdx.x - o] : 0;
         __syncthreads();
-        int off = base;
-        for (int w = 0; w < wave; ++w) off += wtot[w];
-        if (is_root) rank[s] = off + __popcll(mk & ((1ull << lane) - 1ull));
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int tot = 0;
-            for (int w = 0; w < 16; ++w) tot += wtot[w];
-            base += tot;
-        }
+        cnt[threadIdx.x] += t;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *n_tracks = base;
+    int id = cnt[threadIdx.x] - c;
+    for (long s = lo; s < hi; ++s)
+        if (root[s] == (int)s) rank[s] = id++;
+    if (threadIdx.x == 1023) *n_tracks = cnt[1023];
 }
 
 __global__ void chain_assign_kernel(const int *__restrict__ root, const int *__restrict__ rank, int *__restrict__ track, long n)
@@ -370,6 +364,59 @@ __global__ void chain_assign_kernel(const int *__restrict__ root, const int *__r
     if (s >= n) return;
     const int r = root[s];
     track[s] = (r < 0) ? -1 : rank[r];
+}
+
+// The whole chain numbering in ONE launch for small problems (n <= 64 k slots): one workgroup walks the slots in
+// strides, workgroup barriers separate the pointer-doubling rounds (a CU's L1 is coherent for its own workgroup).
+// Replaces 3 + log2(frames) launches whose run time was mostly launch gaps.
+__global__ __launch_bounds__(1024) void chain_small_kernel(const int *__restrict__ count, int n_frames, int cap,
+                                                           const int *__restrict__ pred1, const int *__restrict__ pred2,
+                                                           int *__restrict__ ra, int *__restrict__ rb, int *__restrict__ track,
+                                                           int *__restrict__ n_tracks)
+{
+    __shared__ int cnt[1024];
+    const long n = (long)n_frames * cap;
+    for (long s = threadIdx.x; s < n; s += 1024) {
+        const int t = s / cap, i = s - (long)t * cap;
+        int r = -1;
+        if (i < min(count[t], cap)) {
+            const int p1 = (t >= 1) ? pred1[s] : -1;
+            const int p2 = (t >= 2) ? pred2[s] : -1;
+            r = (p1 >= 0) ? (t - 1) * cap + p1 : (p2 >= 0) ? (t - 2) * cap + p2 : (int)s;
+        }
+        ra[s] = r;
+    }
+    __syncthreads();
+    int *in = ra, *out = rb;
+    for (int span = 1; span < n_frames; span *= 2) {
+        for (long s = threadIdx.x; s < n; s += 1024) {
+            const int r = in[s];
+            out[s] = (r < 0) ? -1 : in[r];
+        }
+        __syncthreads();
+        int *tmp = in; in = out; out = tmp;
+    }
+    // rank of the roots in slot order, then every slot takes its root's rank
+    const long per = (n + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+    int c = 0;
+    for (long s = lo; s < hi; ++s) c += in[s] == (int)s;
+    cnt[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int t = threadIdx.x >= o ? cnt[threadIdx.x - o] : 0;
+        __syncthreads();
+        cnt[threadIdx.x] += t;
+        __syncthreads();
+    }
+    int id = cnt[threadIdx.x] - c;
+    for (long s = lo; s < hi; ++s)
+        if (in[s] == (int)s) out[s] = id++;
+    if (threadIdx.x == 1023) *n_tracks = cnt[1023];
+    __syncthreads();
+    for (long s = threadIdx.x; s < n; s += 1024) {
+        const int r = in[s];
+        track[s] = (r < 0) ? -1 : out[r];
+    }
 }
 
 __global__ void fill_int_kernel(int *p, long n, int v)
@@ -449,6 +496,12 @@ extern "C" int axt_chain_tracks(const int32_t *d_count, int n_frames, int cap, c
     const int *pred1 = d_pred, *pred2 = d_pred + slots;
     const unsigned nb = (unsigned)((slots + 255) / 256);
     int *ra = d_work, *rb = d_work + slots;
+    if (slots <= 65536) {
+        hipLaunchKernelGGL(chain_small_kernel, dim3(1), dim3(1024), 0, st, d_count, n_frames, cap, pred1, pred2, ra, rb, d_track,
+                           d_n_tracks);
+        AXT_LAUNCH_CHECK();
+        return AXT_OK;
+    }
     hipLaunchKernelGGL(chain_init_kernel, dim3(nb), dim3(256), 0, st, d_count, n_frames, cap, pred1, pred2, ra);
     AXT_LAUNCH_CHECK();
     for (int span = 1; span < n_frames; span *= 2) {

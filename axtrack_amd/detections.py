@@ -91,7 +91,7 @@ class AxonDetections(object):
             self._set_detections_from_tables(self.from_cache('_detections'))
             return
         frames = self.dataset.frames
-        self.tile_yx = hp.tile_occupancy(frames)
+        self.tile_yx = self.dataset.tile_yx
         if not self.tile_yx:
             raise ValueError('the timelapse is empty (no tile has a non-zero pixel)')
         self._yolo = self.model.detect_frames(frames, self.tile_yx, 0, self.dataset.sizet)

@@ -41,6 +41,16 @@ class Timelapse:
         return self.sizet
 
     @property
+    def tile_yx(self):
+        """Row-major list of the (tile_row, tile_col) that hold a non-zero pixel at some time point: the reference's
+        tile_info, which construct_tiles computes once when the dataset is built (Timelapse.py:551-558), not in
+        inference(). Computed on the GPU (axt_tile_occupancy) on first use and kept with the timelapse."""
+        if getattr(self, '_tile_yx', None) is None:
+            from . import hotpath as hp
+            self._tile_yx = hp.tile_occupancy(self.frames)
+        return self._tile_yx
+
+    @property
     def device(self):
         return self.frames.device
 

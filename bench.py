@@ -4,8 +4,9 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path (axtrack_amd.inference: tile occupancy -> CNN forward ->
-decode/stitch/NMS -> [all-gather] -> arcs + observation costs -> min-cost-flow -> IDed_dets_all)
+One "step" = one pass of the hot path (axtrack_amd.inference: CNN forward -> decode/stitch/NMS ->
+[all-gather] -> association -> IDed_dets_all; the list of non-empty tiles belongs to the dataset, as in the
+reference, and is computed once when the timelapse is first used)
 over a synthetic 512x512 timelapse that is already resident in HBM. Default workload is BASELINE
 config "c3" (512x512x256, detection + association); "c2" is detection only.
 

@@ -285,10 +285,10 @@ def test_full_size_properties_c3(weights):
 
 
 # ----------------------------------------------------------------------------------------- config 3 variant
-def _hungarian_tracks(dets, H, W):
+def _hungarian_tracks(dets, H, W, cap=None):
     from axtrack_amd.detections import transition_cost_table
     F = len(dets)
-    cap = max(len(d[0]) for d in dets) + 3
+    cap = cap or max(len(d[0]) for d in dets) + 3
     x = np.zeros((F, cap), np.int32); y = np.zeros((F, cap), np.int32)
     for t, d in enumerate(dets):
         x[t, :len(d[1])] = d[1]; y[t, :len(d[2])] = d[2]
@@ -324,6 +324,20 @@ def test_hungarian_association_random_frames(seed):
         dets.append((conf, rng.integers(-5, 300, n), rng.integers(0, 300, n)))
     got, n = _hungarian_tracks(dets, 300, 300)
     ref = orc.hungarian_assoc(dets, 300, 300)
+    assert n == len(ref) and got == ref
+
+
+def test_hungarian_association_wide_and_long():
+    """cap = 576 (four tiles) x 130 frames: more than 192 detection slots per frame (search state in LDS instead of
+    registers) and more than 64 k slots (chain numbering by multi-launch pointer doubling instead of one workgroup)."""
+    rng = np.random.default_rng(77)
+    dets = []
+    for t in range(130):
+        n = int(rng.integers(0, 14)) if t % 17 else 230          # mostly sparse, a few crowded frames (> 192)
+        conf = np.sort(rng.uniform(0.55, 1.2, n).astype(np.float32))[::-1]
+        dets.append((conf, rng.integers(0, 1024, n), rng.integers(0, 1024, n)))
+    got, n = _hungarian_tracks(dets, 1024, 1024, cap=576)
+    ref = orc.hungarian_assoc(dets, 1024, 1024)
     assert n == len(ref) and got == ref
 
 
