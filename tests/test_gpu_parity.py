@@ -329,7 +329,7 @@ def test_hungarian_association_random_frames(seed):
 
 def test_hungarian_association_wide_and_long():
     """cap = 576 (four tiles) x 130 frames: more than 192 detection slots per frame (search state in LDS instead of
-    registers) and more than 64 k slots (chain numbering by multi-launch pointer doubling instead of one workgroup)."""
+    registers) and more than 8 k slots (chain numbering by multi-launch pointer doubling instead of one workgroup)."""
     rng = np.random.default_rng(77)
     dets = []
     for t in range(130):
