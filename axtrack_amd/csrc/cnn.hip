@@ -572,25 +572,46 @@ __global__ __launch_bounds__(256) void gemm_mfma(const float *__restrict__ A, in
 
     // staging assignments: A tile 64 rows x 32 k as float2 (1024 float2 -> 4 per thread)
     //                      B tile 32 k x 64 n as float4 (512 float4 -> 2 per thread)
+    // The next tile's global loads are issued into registers before the MFMAs of the current one and written to LDS
+    // after them (the weight stream of the first linear layer is 168 MB: its latency must hide behind the MFMAs).
+    float2 av[4];
+    f32x4 bv[2];
+    const float *ap[4];
+    const float *bp[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + i * 256;
+        const int r = e >> 4, c2 = e & 15;
+        int gm = m0 + r;
+        gm = gm < M ? gm : M - 1;
+        ap[i] = A + (long)gm * lda + c2 * 2;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = tid + i * 256;
+        bp[i] = Bm + (long)(e >> 4) * N + n0 + (e & 15) * 4;
+    }
+    auto load_tile = [&](int k) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const float2 *>(ap[i] + k);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) bv[i] = *reinterpret_cast<const f32x4 *>(bp[i] + (long)k * N);
+    };
+    load_tile(k0);
     for (int k = k0; k < k0 + kper; k += GBK) {
-        __syncthreads();
+        if (k != k0) __syncthreads();            // every wave is done reading the previous tile
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int e = tid + i * 256;
-            const int r = e >> 4, c2 = e & 15;
-            int gm = m0 + r;
-            gm = gm < M ? gm : M - 1;
-            const float2 v = *reinterpret_cast<const float2 *>(A + (long)gm * lda + k + c2 * 2);
-            *reinterpret_cast<float2 *>(&As[r * GLDA + c2 * 2]) = v;
+            *reinterpret_cast<float2 *>(&As[(e >> 4) * GLDA + (e & 15) * 2]) = av[i];
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int e = tid + i * 256;
-            const int r = e >> 4, c4 = e & 15;
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(Bm + (long)(k + r) * N + n0 + c4 * 4);
-            *reinterpret_cast<f32x4 *>(&Bs[r * GLDB + c4 * 4]) = v;
+            *reinterpret_cast<f32x4 *>(&Bs[(e >> 4) * GLDB + (e & 15) * 4]) = bv[i];
         }
         __syncthreads();
+        if (k + GBK < k0 + kper) load_tile(k + GBK);
 #pragma unroll
         for (int s = 0; s < GBK / 4; ++s) {
             float a[2], bw[2];
