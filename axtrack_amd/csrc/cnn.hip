@@ -310,8 +310,8 @@ struct GeoS2 {
     static constexpr int TH = 16, TW = 32;
 };
 
-template <int CIN, int COUT, int NPC, bool FIRST, int PF>
-__global__ __launch_bounds__(256, 2) void conv3x3_s2_k1(
+template <int CIN, int COUT, int NPC, bool FIRST, int PF, int WGS>
+__global__ __launch_bounds__(256, WGS) void conv3x3_s2_k1(
     const float *__restrict__ in, const float *__restrict__ wpk, const float *__restrict__ bias,
     float *__restrict__ out, int Hin, int B,
     int Hf, int Wf, int t0, int tstep, int item0, int n_tiles, TileList tl)
@@ -796,12 +796,12 @@ int launch_conv(const float *in, const float *w, const float *bias, float *out, 
     return AXT_OK;
 }
 
-template <int CIN, int COUT, int NPC, bool FIRST, int PF>
+template <int CIN, int COUT, int NPC, bool FIRST, int PF, int WGS = 2>
 int launch_conv_s2(const float *in, const float *w, const float *bias, float *out, int Hin, int B,
                    hipStream_t st, int Hf = 0, int Wf = 0, int t0 = 0, int tstep = 1, int item0 = 0, int n_tiles = 1,
                    const TileList *tl = nullptr)
 {
-    auto kern = conv3x3_s2_k1<CIN, COUT, NPC, FIRST, PF>;
+    auto kern = conv3x3_s2_k1<CIN, COUT, NPC, FIRST, PF, WGS>;
     using G = GeoS2<COUT>;
     constexpr size_t lds = (size_t)(4 * (NPC * G::PLANE + 40) + CIN * 9 * 4 * G::NGP + COUT) * sizeof(float);
     static bool attr_set = false;
