@@ -182,16 +182,24 @@ __global__ __launch_bounds__(64) void hungarian_pair_kernel(
                 if (rd < best_dummy) { best_dummy = rd; dummy_row = cur; }
                 long bkey = HINF;
                 int bidx = 0x7fffffff;
+                // branch-free over the lane's columns: the cost reads go out together, everything else is selects
+                long cst[NS];
 #pragma unroll
                 for (int k = 0; k < NS; ++k) {
                     const int j = lane + 64 * k;
-                    if (sc_r[k] || !ok_r[k]) continue;
-                    const long c = cached ? ccache[cur * cdim + j] : link_cost(cur, j);
-                    if (c != HINF) {
-                        const long r = minVal + c - ucur - v_r[k];
-                        if (r < spc_r[k]) { spc_r[k] = r; pred_r[k] = cur; }
-                    }
-                    if (spc_r[k] < bkey) { bkey = spc_r[k]; bidx = j; }
+                    cst[k] = !ok_r[k] ? HINF : cached ? ccache[cur * cdim + j] : link_cost(cur, j);
+                }
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    const bool open = ok_r[k] && !sc_r[k];
+                    const long r = minVal + cst[k] - ucur - v_r[k];
+                    const bool upd = open && cst[k] != HINF && r < spc_r[k];
+                    spc_r[k] = upd ? r : spc_r[k];
+                    pred_r[k] = upd ? cur : pred_r[k];
+                    const long cand = open ? spc_r[k] : HINF;
+                    const bool better = cand < bkey;
+                    bkey = better ? cand : bkey;
+                    bidx = better ? lane + 64 * k : bidx;
                 }
                 wave_argmin(bkey, bidx);
                 if (best_dummy <= bkey) { sink = -2; minVal = best_dummy; break; }

@@ -22,5 +22,18 @@ int main()
             float ms; hipEventElapsedTime(&ms, e0, e1);
             printf("%s %.3f ms  %.2f TB/s\n", which == 0 ? "write 1.32 GB" : which == 1 ? "read 1.32 GB " : "copy 1.32 GB (r+w 2.64)", ms, (which == 2 ? 2 : 1) * bytes / ms / 1e9);
         }
+    // the same three streams over a buffer that fits the 256 MB Infinity Cache (84 MB = block-0 output of 16 tile-forwards)
+    const long small = 84l << 20, ns = small / 16;
+    for (int which = 0; which < 3; ++which) {
+        hipEventRecord(e0);
+        for (int rep = 0; rep < 16; ++rep) {
+            if (which == 0) hipLaunchKernelGGL(wr, dim3(4096), dim3(256), 0, 0, a, ns);
+            if (which == 1) hipLaunchKernelGGL(rd, dim3(4096), dim3(256), 0, 0, a, ns, b);
+            if (which == 2) hipLaunchKernelGGL(cp, dim3(4096), dim3(256), 0, 0, a, b, ns);
+        }
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("84 MB x16 %s %.3f ms  %.2f TB/s\n", which == 0 ? "write" : which == 1 ? "read " : "copy ", ms, (which == 2 ? 2 : 1) * 16.0 * small / ms / 1e9);
+    }
     return 0;
 }
