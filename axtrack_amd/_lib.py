@@ -51,6 +51,8 @@ SIGNATURES = {
                                     c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'axt_chain_tracks': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'axt_ided_table': (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'axt_detection_confusion': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                        c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'axt_arc_cost_int': (c_int64, [c_double, c_int, c_int64, c_int64]),
 }
 

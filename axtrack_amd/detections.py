@@ -178,8 +178,16 @@ class AxonDetections(object):
         elif which_dets == 'IDed':
             assert self._IDed_detections, "Run .assign_IDs() first!"
             det = self._IDed_detections[t]
+        elif which_dets == 'groundtruth':
+            if not self.labelled:
+                raise ValueError("no labels: call set_groundtruth() first")
+            gx, gy = self._gt[t]
+            det = pd.DataFrame({'conf': pd.array(np.ones(len(gx), np.float32), dtype='Float32'),
+                                'anchor_x': pd.array(np.asarray(gx, np.int64), dtype='Int64'),
+                                'anchor_y': pd.array(np.asarray(gy, np.int64), dtype='Int64')},
+                               index=[f'Axon_{i:0>3}' for i in range(len(gx))])
         else:
-            raise NotImplementedError(f"which_dets={which_dets!r} needs labels (out of scope)")
+            raise NotImplementedError(f"which_dets={which_dets!r} is a plotting selection (out of scope)")
         if libmot:
             return self.det2libmot_det(det, t)
         return det.copy()
@@ -194,6 +202,69 @@ class AxonDetections(object):
         det_libmot = np.stack([frame_id, axon_id, x - half, y - half, boxs, boxs, conf]).T
         cols = ['FrameId', 'Id', 'X', 'Y', 'Width', 'Height', 'conf']
         return pd.DataFrame(det_libmot, columns=cols).set_index(['FrameId', 'Id'])
+
+    # ------------------------------------------------------------------ detection metrics (AxonDetections.py:378-503)
+    def set_groundtruth(self, labels):
+        """labels: per detection frame a pair (x, y) of integer anchor arrays. The reference reads them from the
+        labelled dataset's YOLO targets (get_frame_and_truedets, :355-376); the dataset side is out of scope here."""
+        if len(labels) != len(self):
+            raise ValueError(f'{len(labels)} label frames for {len(self)} detection frames')
+        self._gt = [(np.asarray(x, np.int64), np.asarray(y, np.int64)) for x, y in labels]
+        gcap = max([len(x) for x, _ in self._gt] + [1])
+        gx = np.zeros((len(self), gcap), np.int32); gy = np.zeros((len(self), gcap), np.int32)
+        for t, (x, y) in enumerate(self._gt):
+            gx[t, :len(x)] = x; gy[t, :len(y)] = y
+        dev = self.device
+        self._gt_dev = (torch.from_numpy(gx).to(dev), torch.from_numpy(gy).to(dev),
+                        torch.tensor([len(x) for x, _ in self._gt], dtype=torch.int32, device=dev))
+        self.labelled = True
+
+    def detection_confusion(self):
+        """compute_TP_FP_FN('all', t) of every frame in one launch: int array [frames, 3 (TP, FP, FN), 13 thresholds]."""
+        if not self.labelled:
+            raise ValueError("no labels: call set_groundtruth() first")
+        return hp.detection_confusion(self.d_conf, self.d_x, self.d_y, self.d_count, *self._gt_dev, self.all_conf_thrs,
+                                      self.nms_min_dist).cpu().numpy().astype(np.int64)
+
+    def compute_TP_FP_FN(self, which_dets, t, return_FP_FN_mask=False):
+        """AxonDetections.py:409-466 for one frame and one selection of detections ('all', 'confident', 'IDed')."""
+        det = self.get_frame_dets(which_dets, t)
+        dev = self.device
+        n = len(det)
+        conf = torch.zeros((1, max(n, 1)), dtype=torch.float32, device=dev)
+        x = torch.zeros((1, max(n, 1)), dtype=torch.int32, device=dev); y = torch.zeros_like(x)
+        if n:
+            conf[0, :n] = torch.from_numpy(det.conf.to_numpy(dtype=np.float32))
+            x[0, :n] = torch.from_numpy(det.anchor_x.to_numpy(dtype=np.int32))
+            y[0, :n] = torch.from_numpy(det.anchor_y.to_numpy(dtype=np.int32))
+        cnt = torch.tensor([n], dtype=torch.int32, device=dev)
+        gx, gy, gc = (v[t:t + 1].contiguous() for v in self._gt_dev)
+        k = int(np.where(self.all_conf_thrs == self.conf_thr)[0][0]) if return_FP_FN_mask else -1
+        res = hp.detection_confusion(conf, x, y, cnt, gx, gy, gc, self.all_conf_thrs, self.nms_min_dist, k)
+        if return_FP_FN_mask:
+            _, fp, fn = res
+            return fp[0, :n].cpu().numpy().astype(bool), fn[0, :int(gc.item())].cpu().numpy().astype(bool)
+        return res[0].cpu().numpy().astype(np.int64)
+
+    def compute_prc_rcl_F1(self, cnfs_mtrx, return_dataframe=False):
+        """AxonDetections.py:468-503 (host arithmetic, three lines)."""
+        prc = cnfs_mtrx[0] / (cnfs_mtrx[0] + cnfs_mtrx[1] + 1e-6)
+        rcl = cnfs_mtrx[0] / (cnfs_mtrx[0] + cnfs_mtrx[2] + 1e-6)
+        f1 = 2 * (prc * rcl) / ((prc + rcl) + 1e-6)
+        metric = np.array([prc, rcl, f1]).round(3)
+        if return_dataframe:
+            index = pd.MultiIndex.from_product([('precision', 'recall', 'F1'), self.all_conf_thrs])
+            return pd.Series(metric.flatten(), index=index)
+        return metric
+
+    def get_detection_metrics(self, which_dets, t, return_all_conf_thrs=False):
+        """AxonDetections.py:378-407"""
+        if not self.labelled:
+            return None, None, None
+        prc_rcl_f1 = self.compute_prc_rcl_F1(self.compute_TP_FP_FN(which_dets, t))
+        if not return_all_conf_thrs:
+            return prc_rcl_f1[:, np.where(self.all_conf_thrs == self.conf_thr)[0][0]]
+        return prc_rcl_f1
 
     # ------------------------------------------------------------------ association (AxonDetections.py:505-524)
     def assign_ids(self, astar_paths_cache=None, assigedIDs_cache=None):

@@ -340,6 +340,26 @@ def ided_table(track, conf, x, y, count, n_ids, label_quirk=True, id_row=None, n
     return host.numpy()
 
 
+def detection_confusion(conf, x, y, count, gx, gy, gcount, thrs, min_dist=23, k_mask=-1):
+    """compute_TP_FP_FN (AxonDetections.py:409-466) for all frames and thresholds at once: i32 [F,3,n_thr] on the
+    device (TP, FP, FN); with k_mask >= 0 also (fp_mask u8 [F,cap], fn_mask u8 [F,gcap]) for that threshold."""
+    n_frames, cap = x.shape
+    gcap = gx.shape[1]
+    dev = x.device
+    th = torch.as_tensor(np.ascontiguousarray(thrs, np.float64)).to(dev)
+    out = torch.zeros((n_frames, 3, len(th)), dtype=torch.int32, device=dev)
+    fp = fn = None
+    if k_mask >= 0:
+        fp = torch.zeros((n_frames, cap), dtype=torch.uint8, device=dev)
+        fn = torch.zeros((n_frames, gcap), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().axt_detection_confusion(conf.data_ptr(), x.data_ptr(), y.data_ptr(), count.data_ptr(), n_frames,
+                                                       cap, gx.data_ptr(), gy.data_ptr(), gcount.data_ptr(), gcap,
+                                                       th.data_ptr(), len(th), int(min_dist), int(k_mask), out.data_ptr(),
+                                                       _lib.dptr(fp), _lib.dptr(fn), _stream()), 'axt_detection_confusion')
+    return (out, fp, fn) if k_mask >= 0 else out
+
+
 def arc_cost_int(cost, kind, a, b):
     return int(_lib.load().axt_arc_cost_int(float(cost), int(kind), int(a), int(b)))
 

@@ -260,6 +260,21 @@ int axt_ided_table(const int32_t *d_track, const float *d_conf, const int32_t *d
                    const int32_t *d_count, int n_frames, int cap, int n_ids, const int32_t *d_id_row, int n_rows,
                    int label_quirk, int32_t *d_work, double *d_table, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Detection metrics: compute_TP_FP_FN (AxonDetections.py:409-466) for every frame
+ * and every confidence threshold. Detections as axt_decode_stitch_nms leaves them; labels d_gx, d_gy
+ * i32 [n_frames, gcap], d_gcount i32 [n_frames]; d_thrs f64 [n_thr] on the device (the reference's
+ * all_conf_thrs, :76); min_dist = NON_MAX_SUPRESSION_DIST. d_confusion i32 [n_frames, 3, n_thr]:
+ * TP, FP, FN. Labels are matched in order; a label whose closest candidate is already claimed is a
+ * false negative; an empty side is replaced by one phantom row at the origin with conf 0 (:434-437).
+ * k_mask >= 0: additionally d_fp_mask u8 [n_frames, cap] / d_fn_mask u8 [n_frames, gcap] for that
+ * threshold index (either may be NULL). Asynchronous.
+ * ------------------------------------------------------------------------------------------ */
+int axt_detection_confusion(const float *d_conf, const int32_t *d_x, const int32_t *d_y, const int32_t *d_count,
+                            int n_frames, int cap, const int32_t *d_gx, const int32_t *d_gy, const int32_t *d_gcount,
+                            int gcap, const double *d_thrs, int n_thr, int min_dist, int k_mask,
+                            int32_t *d_confusion, uint8_t *d_fp_mask, uint8_t *d_fn_mask, void *stream);
+
 /* Integer arc cost used by the flow network: round(cost * 1e6) << 16 | hash16(kind, a, b).
  * kind 0 entry, 1 exit, 2 observation, 3 transition. The low 16 bits make the optimum unique
  * (DESIGN.md "Unpinned third-party semantics"). */

@@ -504,6 +504,61 @@ def ided_dets_all(tables, reproduce_label_quirk=True):
 
 
 # ------------------------------------------------------------------------------- whole path
+# ------------------------------------------------------------------------------- f-4 (next row)
+def all_conf_thrs(bbox_thr=0.7):
+    """AxonDetections.py:76"""
+    return np.sort(np.append(np.arange(0.55, 1, .04), bbox_thr)).round(2)
+
+
+def detection_confusion(det, gt_x, gt_y, thrs=None, min_dist=23, return_masks_at=None):
+    """compute_TP_FP_FN (AxonDetections.py:409-466) for one frame: int [3 (TP, FP, FN), len(thrs)].
+    det = (conf f32, x, y) in descending confidence; ground truth anchors gt_x, gt_y. Restated with its quirks:
+      * an empty side is replaced by ONE row (conf, x, y) = (0, 0, 0) (:434-437) -- a phantom label / detection at
+        the origin that takes part in the matching;
+      * per label, the candidates are the detections closer than min_dist (sqrt(dx^2+dy^2) < 23, exact for integer
+        anchors) with conf > thr (f32 conf against the f64 threshold, compared in f64 as numpy >= 2 does); the
+        closest wins, ties to the first;
+      * labels are visited in order; a label whose closest candidate was already claimed by an earlier label is a
+        false negative -- it does NOT fall back to its second-closest candidate (:447-452).
+    return_masks_at: threshold index -> (FP mask over detections, FN mask over labels) instead (:462-465)."""
+    thrs = all_conf_thrs() if thrs is None else np.asarray(thrs, np.float64)
+    conf, x, y = (np.asarray(v) for v in det)
+    if len(conf) == 0:
+        conf, x, y = np.zeros(1, np.float32), np.zeros(1, np.int64), np.zeros(1, np.int64)
+    gt_x, gt_y = np.asarray(gt_x, np.int64), np.asarray(gt_y, np.int64)
+    if len(gt_x) == 0:
+        gt_x, gt_y = np.zeros(1, np.int64), np.zeros(1, np.int64)
+    d2 = (gt_x[:, None] - np.asarray(x, np.int64)[None]) ** 2 + (gt_y[:, None] - np.asarray(y, np.int64)[None]) ** 2
+    c64 = np.asarray(conf, np.float32).astype(np.float64)
+    out = np.zeros((3, len(thrs)), np.int64)
+    for k, thr in enumerate(thrs):
+        above = c64 > thr
+        tp = np.zeros(len(c64), bool)
+        taken = []
+        fn = np.zeros(len(gt_x), bool)
+        for i in range(len(gt_x)):
+            cand = np.nonzero((d2[i] < min_dist * min_dist) & above)[0]
+            best = int(cand[np.argmin(d2[i][cand])]) if len(cand) else -1
+            if best >= 0 and best not in taken:
+                taken.append(best)
+            else:
+                fn[i] = True
+        tp[taken] = True
+        fp = ~tp & above
+        out[:, k] = tp.sum(), fp.sum(), fn.sum()
+        if return_masks_at is not None and k == return_masks_at:
+            return fp, fn
+    return out
+
+
+def prc_rcl_f1(cm):
+    """compute_prc_rcl_F1 (AxonDetections.py:468-503)."""
+    prc = cm[0] / (cm[0] + cm[1] + 1e-6)
+    rcl = cm[0] / (cm[0] + cm[2] + 1e-6)
+    f1 = 2 * (prc * rcl) / ((prc + rcl) + 1e-6)
+    return np.array([prc, rcl, f1]).round(3)
+
+
 def inference(frames, sd, mask=None, P=DEFAULTS, name='synth', yolo=None, assoc='mcf'):
     """interface.inference (interface.py:170-215): detect_dataset + assign_ids.
     assoc='mcf' is the reference's global tracker; 'hungarian' the BASELINE config 3 variant."""

@@ -279,9 +279,59 @@ def gen_assoc_parts(tl, ad):
     save('assoc_parts.npz', **out)
 
 
+
+def gen_metrics(ad):
+    """f-4: compute_TP_FP_FN / compute_prc_rcl_F1 (AxonDetections.py:409-503) run by the reference
+    itself on the detections of detect_1024 against synthetic ground truth: jittered copies of every other
+    detection (some exactly at, some just inside / outside the 23 px radius), clustered labels that compete for one
+    detection, labels with no detection nearby, and one frame without labels."""
+    rng = np.random.default_rng(7)
+    nfr = len(ad)
+    gts = []
+    for t in range(nfr):
+        det = ad._detections[t]
+        x = det.anchor_x.to_numpy(dtype=np.int64); y = det.anchor_y.to_numpy(dtype=np.int64)
+        gx, gy = [], []
+        for k in range(0, len(det), 2):
+            r = int(rng.integers(0, 6))
+            dx, dy = [(0, 0), (23, 0), (22, 0), (16, 16), (17, 16), (-5, 9)][r]
+            gx.append(x[k] + dx); gy.append(y[k] + dy)
+            if k % 10 == 0:                                  # a second label next to the same detection
+                gx.append(x[k] + 3); gy.append(y[k] - 2)
+        for _ in range(5):                                   # labels far from everything
+            gx.append(int(rng.integers(0, 1024))); gy.append(int(rng.integers(0, 1024)))
+        if t == 2:
+            gx, gy = [], []
+        gts.append(pd.DataFrame({'conf': pd.array(np.ones(len(gx), np.float32), dtype='Float32'),
+                                 'anchor_x': pd.array(np.array(gx, np.int64), dtype='Int64'),
+                                 'anchor_y': pd.array(np.array(gy, np.int64), dtype='Int64')},
+                                index=[f'Axon_{i:0>3}' for i in range(len(gx))]))
+    orig = ad.get_frame_dets
+    ad.get_frame_dets = lambda which, t, *a, **k: gts[t].copy() if which == 'groundtruth' else orig(which, t, *a, **k)
+    ad.labelled = True
+    out = {'gt_counts': np.array([len(g) for g in gts], np.int64),
+           'gt_x': np.concatenate([g.anchor_x.to_numpy(dtype=np.int64) for g in gts]),
+           'gt_y': np.concatenate([g.anchor_y.to_numpy(dtype=np.int64) for g in gts]),
+           'all_conf_thrs': np.asarray(ad.all_conf_thrs, np.float64), 'nms_min_dist': np.array(ad.nms_min_dist)}
+    cm, prf, fp_masks, fn_masks = [], [], [], []
+    for t in range(nfr):
+        c = ad.compute_TP_FP_FN('all', t)
+        cm.append(c)
+        prf.append(ad.compute_prc_rcl_F1(c))
+        fp, fn = ad.compute_TP_FP_FN('all', t, return_FP_FN_mask=True)
+        fp_masks.append(np.asarray(fp, bool)); fn_masks.append(np.asarray(fn, bool))
+    out['confusion'] = np.array(cm, np.int64)                 # [frames, 3 (TP, FP, FN), 13 thresholds]
+    out['prc_rcl_f1'] = np.array(prf, np.float64)
+    out['fp_mask_at_bbox_thr'] = np.concatenate(fp_masks)
+    out['fn_mask_at_bbox_thr'] = np.concatenate(fn_masks)
+    ad.get_frame_dets = orig
+    save('metrics.npz', **out)
+
+
 if __name__ == '__main__':
     gen_cnn_512()
     tl, ad = gen_detect('detect_1024', 7, 1024, 1024, seed=1)
     gen_assoc_parts(tl, ad)
+    gen_metrics(ad)
     gen_detect('detect_ragged', 6, 700, 1100, seed=2, zero_tile=(1, 2))
     gen_detect_crafted()

@@ -510,6 +510,46 @@ def test_inference_with_appearance_term(weights):
     assert ad0.mcf_total_cost != ad.mcf_total_cost
 
 
+# ----------------------------------------------------------------------------------------- f-4 (next row)
+def test_detection_metrics_match_the_reference(golden):
+    """compute_TP_FP_FN over all frames and the 13 thresholds in one launch, and the per-frame API, against what the
+    reference itself returned (tests/golden/metrics.npz) -- including the frame without labels (phantom label at
+    the origin) and the FP / FN masks at BBOX_THRESHOLD."""
+    import axtrack_amd, pandas as pd
+    from axtrack_amd.detections import AxonDetections
+    g, m = golden('detect_1024'), golden('metrics')
+    dets = golden_dets(g)
+    tl = axtrack_amd.Timelapse(np.zeros((len(dets) + 4, 1024, 1024), np.float32), name='synth')
+    ad = AxonDetections(None, tl, params.load_parameters(), None)
+    ad._set_detections_from_tables([pd.DataFrame({'conf': c, 'anchor_x': x, 'anchor_y': y}) for c, x, y in dets])
+    offs = np.concatenate([[0], np.cumsum(m['gt_counts'])])
+    ad.set_groundtruth([(m['gt_x'][offs[t]:offs[t + 1]], m['gt_y'][offs[t]:offs[t + 1]]) for t in range(len(dets))])
+    assert np.array_equal(ad.all_conf_thrs, m['all_conf_thrs'])
+    cm = ad.detection_confusion()
+    assert np.array_equal(cm, m['confusion'])
+    doffs = np.concatenate([[0], np.cumsum(g['counts'])])
+    for t in range(len(dets)):
+        one = ad.compute_TP_FP_FN('all', t)
+        assert np.array_equal(one, m['confusion'][t])
+        assert np.array_equal(ad.compute_prc_rcl_F1(one), m['prc_rcl_f1'][t])
+        assert np.array_equal(ad.get_detection_metrics('all', t, True), m['prc_rcl_f1'][t])
+        fp, fn = ad.compute_TP_FP_FN('all', t, return_FP_FN_mask=True)
+        assert np.array_equal(fp, m['fp_mask_at_bbox_thr'][doffs[t]:doffs[t + 1]])
+        if m['gt_counts'][t]:
+            lo = offs[t] + sum(1 for q in range(t) if m['gt_counts'][q] == 0)
+            assert np.array_equal(fn, m['fn_mask_at_bbox_thr'][lo:lo + m['gt_counts'][t]])
+    # 'confident' selection and an empty detection side against the oracle
+    conf_t = ad.compute_TP_FP_FN('confident', 0)
+    d0 = dets[0]
+    keep = d0[0] > np.float32(0.7)
+    assert np.array_equal(conf_t, orc.detection_confusion((d0[0][keep], d0[1][keep], d0[2][keep]), *ad._gt[0]))
+    ad2 = AxonDetections(None, tl, params.load_parameters(), None)
+    ad2._set_detections_from_tables([pd.DataFrame({'conf': [], 'anchor_x': [], 'anchor_y': []}) for _ in dets])
+    ad2.set_groundtruth(ad._gt)
+    for t in range(len(dets)):
+        assert np.array_equal(ad2.detection_confusion()[t], orc.detection_confusion(([], [], []), *ad._gt[t]))
+
+
 # ----------------------------------------------------------------------------------------- f-1 (next row)
 def test_preprocess_fused_pass_matches_oracle():
     rng = np.random.default_rng(3)

@@ -5,6 +5,7 @@ import pytest
 
 from axtrack_amd import synth
 from oracle import oracle as orc
+from helpers import golden_dets
 
 # CNN parity is by tolerance: the reference's conv/linear run through oneDNN/MKL with an
 # unspecified f32 summation order (model.py:50-53).
@@ -157,3 +158,24 @@ def test_appearance_features_restatement_is_self_consistent():
     c1 = orc.transition_cost(D, 1, vis_w=0.3, vis_sim=np.array([[1.0, 1.0, 1.0]]))
     c2 = orc.transition_cost(D, 1, vis_w=0.3, vis_sim=np.array([[0.0, 0.0, 0.0]]))
     assert np.all(c1 < c2) and np.all(c1[0, 1:] < c0[0, 1:])
+
+
+def test_detection_metrics_match_the_reference(golden):
+    """f-4: TP/FP/FN over the 13 confidence thresholds and precision/recall/F1, against what the reference's own
+    compute_TP_FP_FN / compute_prc_rcl_F1 returned for the detect_1024 detections and synthetic labels."""
+    g, m = golden('detect_1024'), golden('metrics')
+    dets = golden_dets(g)
+    assert np.array_equal(orc.all_conf_thrs(), m['all_conf_thrs']) and int(m['nms_min_dist']) == 23
+    offs = np.concatenate([[0], np.cumsum(m['gt_counts'])])
+    doffs = np.concatenate([[0], np.cumsum(g['counts'])])
+    k_bbox = int(np.where(m['all_conf_thrs'] == 0.7)[0][0])
+    for t, det in enumerate(dets):
+        gx, gy = m['gt_x'][offs[t]:offs[t + 1]], m['gt_y'][offs[t]:offs[t + 1]]
+        cm = orc.detection_confusion(det, gx, gy)
+        assert np.array_equal(cm, m['confusion'][t]), t
+        assert np.array_equal(orc.prc_rcl_f1(cm), m['prc_rcl_f1'][t])
+        fp, fn = orc.detection_confusion(det, gx, gy, return_masks_at=k_bbox)
+        assert np.array_equal(fp, m['fp_mask_at_bbox_thr'][doffs[t]:doffs[t + 1]])
+        n_gt = max(len(gx), 1)
+        lo = offs[t] + sum(1 for q in range(t) if m['gt_counts'][q] == 0)      # an empty frame contributes one phantom row
+        assert np.array_equal(fn, m['fn_mask_at_bbox_thr'][lo:lo + n_gt])
