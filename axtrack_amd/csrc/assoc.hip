@@ -289,7 +289,8 @@ int axt_path_cost(const int32_t *d_xa, const int32_t *d_ya, int na, const int32_
 static int build_arcs_impl(const int32_t *d_x, const int32_t *d_y, const int32_t *d_count, int n_frames, int cap,
                            const axt_grid *grid, int H, int W, int max_dist, int conn8, int max_gap, const int32_t *h_dmax,
                            int64_t *d_row_ptr, int32_t *d_work, int32_t *d_col, int16_t *d_len, uint8_t *d_gap,
-                           const int64_t *d_cost_units, int64_t *d_cost, int64_t *n_arcs, const VisParams *vis, void *stream)
+                           const int64_t *d_cost_units, int64_t *d_cost, int64_t *n_arcs, const VisParams *vis,
+                           const int16_t *d_ext_table, void *stream)
 {
     AXT_REQUIRE(d_x && d_y && d_count && h_dmax && d_row_ptr && d_work && n_arcs, "null argument");
     AXT_REQUIRE(n_frames >= 1 && cap >= 1 && max_gap >= 1 && max_gap <= 8, "bad argument");
@@ -299,7 +300,10 @@ static int build_arcs_impl(const int32_t *d_x, const int32_t *d_y, const int32_t
     int *cnt = d_work;
     int *frame_off = d_work + (size_t)n_frames * cap * max_gap;
     int *dmax = frame_off + n_frames + 1;
-    short *Dtmp = reinterpret_cast<short *>(d_work + (((size_t)n_frames * cap * max_gap + n_frames + 1 + max_gap + 3) & ~(size_t)3));
+    // path lengths from a table: the caller's (d_ext_table) or the one the masked-grid search fills in d_work
+    const short *Dtmp = d_ext_table ? d_ext_table
+                                    : reinterpret_cast<short *>(d_work + (((size_t)n_frames * cap * max_gap + n_frames + 1 + max_gap + 3) & ~(size_t)3));
+    const bool table = grid != nullptr || d_ext_table != nullptr;
     const dim3 grid_dim(n_frames, 8), block(256);
     const bool fill = d_col != nullptr;
     const VisParams vp = vis ? *vis : VisParams{};
@@ -309,19 +313,19 @@ static int build_arcs_impl(const int32_t *d_x, const int32_t *d_y, const int32_t
                            max_gap, dmax, cnt, fill ? (const long *)d_row_ptr : (const long *)nullptr, fill ? d_col : (int *)nullptr,
                            fill ? d_len : (short *)nullptr, fill ? d_gap : (unsigned char *)nullptr,
                            fill ? (const long *)d_cost_units : (const long *)nullptr, fill ? (long *)d_cost : (long *)nullptr,
-                           grid ? (const short *)Dtmp : (const short *)nullptr, vp);
+                           table ? Dtmp : (const short *)nullptr, vp);
     };
     if (!fill) {
         AXT_CHECK_HIP(hipMemcpyAsync(dmax, h_dmax, sizeof(int) * max_gap, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(frame_offsets_kernel, dim3(1), dim3(1024), 0, st, d_count, n_frames, cap, frame_off);
         AXT_LAUNCH_CHECK();
-        if (grid) {
+        if (grid && !d_ext_table) {
             const int rc = axt_masked_distance_table(grid, d_x, d_y, d_count, n_frames, cap, max_dist, max_gap, h_dmax, dmax,
-                                                     Dtmp, st);
+                                                     const_cast<short *>(Dtmp), st);
             if (rc) return rc;
         }
-        if (grid && vis) launch(arcs_open_kernel<false, true, true>);
-        else if (grid) launch(arcs_open_kernel<false, true, false>);
+        if (table && vis) launch(arcs_open_kernel<false, true, true>);
+        else if (table) launch(arcs_open_kernel<false, true, false>);
         else if (vis) launch(arcs_open_kernel<false, false, true>);
         else launch(arcs_open_kernel<false, false, false>);
         AXT_LAUNCH_CHECK();
@@ -339,8 +343,8 @@ static int build_arcs_impl(const int32_t *d_x, const int32_t *d_y, const int32_t
     }
     AXT_REQUIRE(d_len && d_gap, "null argument");
     AXT_REQUIRE(vis || (d_cost == nullptr) == (d_cost_units == nullptr), "d_cost and d_cost_units go together");
-    if (grid && vis) launch(arcs_open_kernel<true, true, true>);
-    else if (grid) launch(arcs_open_kernel<true, true, false>);
+    if (table && vis) launch(arcs_open_kernel<true, true, true>);
+    else if (table) launch(arcs_open_kernel<true, true, false>);
     else if (vis) launch(arcs_open_kernel<true, false, true>);
     else launch(arcs_open_kernel<true, false, false>);
     AXT_LAUNCH_CHECK();
@@ -353,7 +357,17 @@ int axt_build_arcs(const int32_t *d_x, const int32_t *d_y, const int32_t *d_coun
                    const int64_t *d_cost_units, int64_t *d_cost, int64_t *n_arcs, void *stream)
 {
     return build_arcs_impl(d_x, d_y, d_count, n_frames, cap, grid, H, W, max_dist, conn8, max_gap, h_dmax, d_row_ptr, d_work,
-                           d_col, d_len, d_gap, d_cost_units, d_cost, n_arcs, nullptr, stream);
+                           d_col, d_len, d_gap, d_cost_units, d_cost, n_arcs, nullptr, nullptr, stream);
+}
+
+int axt_build_arcs_from_lengths(const int16_t *d_len_table, const int32_t *d_x, const int32_t *d_y, const int32_t *d_count,
+                                int n_frames, int cap, int max_dist, int max_gap, const int32_t *h_dmax,
+                                int64_t *d_row_ptr, int32_t *d_work, int32_t *d_col, int16_t *d_len, uint8_t *d_gap,
+                                const int64_t *d_cost_units, int64_t *d_cost, int64_t *n_arcs, void *stream)
+{
+    AXT_REQUIRE(d_len_table, "axt_build_arcs_from_lengths: null table");
+    return build_arcs_impl(d_x, d_y, d_count, n_frames, cap, nullptr, 0, 0, max_dist, 0, max_gap, h_dmax, d_row_ptr, d_work,
+                           d_col, d_len, d_gap, d_cost_units, d_cost, n_arcs, nullptr, d_len_table, stream);
 }
 
 int axt_build_arcs_vis(const int32_t *d_x, const int32_t *d_y, const int32_t *d_count, int n_frames, int cap,
@@ -371,7 +385,7 @@ int axt_build_arcs_vis(const int32_t *d_x, const int32_t *d_y, const int32_t *d_
     vp.thr = edge_cost_thr;
     for (int g = 0; g < 8; ++g) vp.mp[g] = pow(miss_rate, (double)g);          // miss_rate ** (gap - 1), as Python computes it
     return build_arcs_impl(d_x, d_y, d_count, n_frames, cap, grid, H, W, max_dist, conn8, max_gap, h_dmax, d_row_ptr, d_work,
-                           d_col, d_len, d_gap, nullptr, d_cost, n_arcs, &vp, stream);
+                           d_col, d_len, d_gap, nullptr, d_cost, n_arcs, &vp, nullptr, stream);
 }
 
 }  // extern "C"

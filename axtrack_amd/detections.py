@@ -10,6 +10,7 @@ whole-array GPU passes instead of a Python loop over frames and DataFrames:
 pandas objects are only materialised at the API boundary (lazily for the per-frame tables).
 """
 import os
+import re
 import pickle
 
 import numpy as np
@@ -268,6 +269,15 @@ class AxonDetections(object):
 
     # ------------------------------------------------------------------ association (AxonDetections.py:505-524)
     def assign_ids(self, astar_paths_cache=None, assigedIDs_cache=None):
+        """AxonDetections.py:505-524. astar_paths_cache: 'from' adopts the path lengths of a
+        '{name}_astar_dets_paths.pkl' (the reference's format: per frame pair a nested list of coo matrices / None)
+        instead of computing them; 'to' writes such a file (all-ones masks only: see astar_dets_paths)."""
+        self._len_table = None
+        if assigedIDs_cache != 'from':
+            if astar_paths_cache == 'from':
+                self._len_table = self._length_table_from_paths(self.from_cache('astar_dets_paths'))
+            elif astar_paths_cache == 'to':
+                self.to_cache('astar_dets_paths', self.astar_dets_paths())
         if assigedIDs_cache == 'from':
             self._set_ided_from_tables(self.from_cache('_IDed_detections'))
         else:
@@ -339,6 +349,58 @@ class AxonDetections(object):
                 out[lbl] = D.cpu().numpy()
         return out
 
+    def _length_table_from_paths(self, paths):
+        """_get_astar_path_distances (AxonDetections.py:717-752) of a cached path dictionary, as the i16 table
+        [F, cap, gaps, cap] axt_build_arcs_from_lengths reads: getnnz() of a path, 0 (= none) for None."""
+        cnt = self._host_dets()[0]
+        F, cap, gaps = len(self), self.d_x.shape[1], self.P['MCF_MAX_NUM_MISSES'] + 1
+        table = np.zeros((F, cap, gaps, cap), np.int16)
+        for t in range(F):
+            for t_bef in range(t - 1, t - (gaps + 1), -1):
+                if t_bef < 0:
+                    continue
+                rows = paths[f'{self.dataset.name}_t:{t:0>3}-t:{t_bef:0>3}']
+                if len(rows) != cnt[t_bef] or any(len(r) != cnt[t] for r in rows):
+                    raise ValueError(f'cached paths of t:{t}-t:{t_bef} do not match the detections')
+                for i, row in enumerate(rows):
+                    table[t_bef, i, t - t_bef - 1, :len(row)] = [0 if p is None else min(p.getnnz(), 32767) for p in row]
+        return torch.from_numpy(table).to(self.device)
+
+    def astar_dets_paths(self):
+        """The reference's path dictionary (_compute_detections_astar_paths, AxonDetections.py:526-585): per frame pair
+        a list over the detections of t_bef of lists over the detections of t of scipy coo matrices [H, W] (bool)
+        marking the cells of a shortest path, or None beyond max_px_assoc_dist. On an all-ones mask every monotone
+        staircase between the two anchors is a shortest path; this one walks the columns first, then the rows (which
+        of the equally short paths pyastar2d returns is unpinned; lengths are what the tracker
+        uses). Masked grids: not materialised (the GPU search keeps distances, not predecessors)."""
+        from scipy import sparse
+        if self.dataset.mask2d is not None:
+            raise NotImplementedError('paths on a masked grid are not materialised; their lengths are (astar_dists)')
+        if self.conn8:
+            raise NotImplementedError('path materialisation is implemented for the 4-connected grid')
+        dists = self.astar_dists()
+        cnt, _, x, y = self._host_dets()
+        H, W = self.dataset.sizey, self.dataset.sizex
+        out = {}
+        for lbl, D in dists.items():
+            t, t_bef = (int(v) for v in re.search(r't:(\d+)-t:(\d+)$', lbl).groups())
+            rows = []
+            for i in range(int(cnt[t_bef])):
+                row = []
+                for j in range(int(cnt[t])):
+                    if D[i, j] >= self.max_px_assoc_dist:
+                        row.append(None)
+                        continue
+                    xa, ya, xb, yb = int(x[t_bef, i]), int(y[t_bef, i]), int(x[t, j]), int(y[t, j])
+                    xs = np.arange(xa, xb + (1 if xb >= xa else -1), 1 if xb >= xa else -1)
+                    ys = np.arange(ya, yb + (1 if yb >= ya else -1), 1 if yb >= ya else -1)
+                    r = np.concatenate([np.full(len(xs), ya), ys[1:]])
+                    c = np.concatenate([xs, np.full(len(ys) - 1, xb)])
+                    row.append(sparse.coo_matrix((np.ones(len(r)), (r, c)), (H, W), bool))
+                rows.append(row)
+            out[lbl] = rows
+        return out
+
     def _appearance(self):
         """feature_model's histograms of every detection (device tensors hist f32 [F,cap,180], sums f64 [F,cap]),
         computed once from the centre frames (AxonDetections.py:682-685)."""
@@ -386,9 +448,12 @@ class AxonDetections(object):
         if vis_w:
             hist, hsum = self._appearance()
             vis = dict(hist=hist, hsum=hsum, weight=vis_w, miss_rate=P['MCF_MISS_RATE'], thr=P['MCF_EDGE_COST_THR'])
+        len_table = getattr(self, '_len_table', None)
+        if len_table is not None and vis is not None:
+            raise NotImplementedError('cached path lengths together with MCF_VIS_SIM_WEIGHT > 0')
         row_ptr, col, length, gap, cost = hp.build_arcs(self.d_x, self.d_y, self.d_count, self.dataset.sizey,
                                                         self.dataset.sizex, dmax, units, self._mask_dev(),
-                                                        self.max_px_assoc_dist, self.conn8, vis)
+                                                        self.max_px_assoc_dist, self.conn8, vis, len_table)
         cnt, conf, x, y = self._host_dets()
         offs = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
         n_det = int(offs[-1])

@@ -238,11 +238,14 @@ def box_histograms(frames, x, y, count, t_offset=2, box=AXON_BOX_SIZE):
     return hist, hsum
 
 
-def build_arcs(x, y, count, H, W, dmax, cost_units=None, mask=None, max_dist=MAX_PX_ASSOC_DIST, conn8=False, vis=None):
+def build_arcs(x, y, count, H, W, dmax, cost_units=None, mask=None, max_dist=MAX_PX_ASSOC_DIST, conn8=False, vis=None,
+               length_table=None):
     """Admissible transition arcs of the whole timelapse, CSR by tail detection (global numbering).
     cost_units: optional int64 [max_gap, max_dist+1] = round(transition cost * 1e6) per (gap, D).
     vis: None, or dict(hist, hsum, weight, miss_rate, thr) -- the appearance term (MCF_VIS_SIM_WEIGHT > 0): costs
     are then computed per pair on the GPU and cost_units is ignored.
+    length_table: None, or i16 device tensor [F, cap, max_gap, cap] of precomputed path lengths (<= 0: none), e.g.
+    from a path cache written by the reference; mask is then ignored.
     Returns device tensors (row_ptr i64 [n_frames*cap+1], col i32, length i16, gap u8, cost i64|None)."""
     n_frames, cap = x.shape
     max_gap = len(dmax)
@@ -250,6 +253,9 @@ def build_arcs(x, y, count, H, W, dmax, cost_units=None, mask=None, max_dist=MAX
     h_dmax = np.ascontiguousarray(dmax, np.int32)
     row_ptr = torch.empty((n_frames * cap + 1,), dtype=torch.int64, device=dev)
     n_work = n_frames * cap * max_gap + n_frames + 1 + max_gap + 4
+    if length_table is not None:
+        assert vis is None and tuple(length_table.shape) == (n_frames, cap, max_gap, cap) and length_table.dtype == torch.int16
+        mask = None
     if mask is not None:
         if not isinstance(mask, Grid):
             mask = Grid(mask.cpu().numpy() if isinstance(mask, torch.Tensor) else mask, conn8, dev)
@@ -264,7 +270,12 @@ def build_arcs(x, y, count, H, W, dmax, cost_units=None, mask=None, max_dist=MAX
     head += (row_ptr.data_ptr(), work.data_ptr())
 
     def call(col, length, gap, cu, cost, what):
-        if vis is None:
+        if length_table is not None:
+            rc = lib.axt_build_arcs_from_lengths(length_table.data_ptr(), x.data_ptr(), y.data_ptr(), count.data_ptr(), n_frames,
+                                                 cap, int(max_dist), max_gap, h_dmax.ctypes.data, row_ptr.data_ptr(),
+                                                 work.data_ptr(), _lib.dptr(col), _lib.dptr(length), _lib.dptr(gap),
+                                                 _lib.dptr(cu), _lib.dptr(cost), ctypes.byref(n_arcs), _stream())
+        elif vis is None:
             rc = lib.axt_build_arcs(*head, _lib.dptr(col), _lib.dptr(length), _lib.dptr(gap), _lib.dptr(cu), _lib.dptr(cost),
                                     ctypes.byref(n_arcs), _stream())
         else:

@@ -175,6 +175,16 @@ int axt_build_arcs(const int32_t *d_x, const int32_t *d_y, const int32_t *d_coun
                    int64_t *d_row_ptr, int32_t *d_work, int32_t *d_col, int16_t *d_len, uint8_t *d_gap,
                    const int64_t *d_cost_units, int64_t *d_cost, int64_t *n_arcs, void *stream);
 
+/* axt_build_arcs with the path lengths supplied by the caller instead of computed: d_len_table i16
+ * [n_frames, cap, max_gap, cap], entry [t][i][g-1][j] = number of cells of the path between detection i of
+ * frame t and detection j of frame t+g, <= 0 = none. This is how path lengths cached by the reference
+ * ('{name}_astar_dets_paths.pkl': coo matrices, length = getnnz(), AxonDetections.py:717-752) re-enter the
+ * pipeline. d_x / d_y are not read for lengths but must be valid [n_frames, cap] arrays. */
+int axt_build_arcs_from_lengths(const int16_t *d_len_table, const int32_t *d_x, const int32_t *d_y, const int32_t *d_count,
+                                int n_frames, int cap, int max_dist, int max_gap, const int32_t *h_dmax,
+                                int64_t *d_row_ptr, int32_t *d_work, int32_t *d_col, int16_t *d_len, uint8_t *d_gap,
+                                const int64_t *d_cost_units, int64_t *d_cost, int64_t *n_arcs, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Appearance term of the transition cost, MCF_VIS_SIM_WEIGHT > 0.
  *

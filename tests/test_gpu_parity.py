@@ -432,6 +432,58 @@ def test_two_rank_frame_sharding(weights):
         assert res[0][mode] == ref and res[1][mode] == ref, mode
 
 
+# ----------------------------------------------------------------------------------------- f-2 (next row)
+def test_path_cache_round_trip_in_the_references_format(weights, tmp_path):
+    """'{name}_astar_dets_paths.pkl': written ('to') in the reference's format -- nested lists of scipy coo matrices /
+    None per frame pair -- read back ('from') through axt_build_arcs_from_lengths, and consumed by the oracle's
+    restatement of _get_astar_path_distances: the same path lengths, arcs and trajectories every way."""
+    import pickle
+    from scipy import sparse
+    frames = synth.synth_frames(9, 512, 512, seed=19)
+    P = params.load_parameters()
+    import axtrack_amd
+    model = axtrack_amd.Detector(weights, max_batch=8)
+    tl = axtrack_amd.Timelapse(frames, name='cachetest')
+    ad = axtrack_amd.AxonDetections(model, tl, P, str(tmp_path))
+    ad.detect_dataset()
+    ad.assign_ids(astar_paths_cache='to')
+    ref_tracks, ref_cost = ad._track_flat.copy(), ad.mcf_total_cost
+    paths = pickle.load(open(tmp_path / 'cachetest_astar_dets_paths.pkl', 'rb'))
+    dists = ad.astar_dists()
+    assert paths.keys() == dists.keys()
+    cnt, _, x, y = ad._host_dets()
+    for lbl, rows in paths.items():
+        D = dists[lbl]
+        for i, row in enumerate(rows):
+            for j, p in enumerate(row):
+                if p is None:
+                    assert D[i, j] == 500
+                    continue
+                assert sparse.isspmatrix_coo(p) and p.shape == (512, 512) and p.dtype == bool
+                assert p.getnnz() == D[i, j]                                  # what _get_astar_path_distances reads
+                r, c = p.row, p.col
+                assert np.all(np.abs(np.diff(r)) + np.abs(np.diff(c)) == 1)   # 4-connected, no cell twice
+    # read it back: same arcs -> same optimum
+    ad2 = axtrack_amd.AxonDetections(model, tl, P, str(tmp_path))
+    ad2.detect_dataset()
+    ad2.assign_ids(astar_paths_cache='from')
+    assert np.array_equal(ad2._track_flat, ref_tracks) and ad2.mcf_total_cost == ref_cost
+    # a cache in which one admissible pair was declared unreachable changes the problem
+    lbl = next(k for k, rows in paths.items() if any(p is not None and p.getnnz() < 100 for r in rows for p in r))
+    i, j = next((i, j) for i, r in enumerate(paths[lbl]) for j, p in enumerate(r) if p is not None and p.getnnz() < 100)
+    paths[lbl][i][j] = None
+    pickle.dump(paths, open(tmp_path / 'cachetest_astar_dets_paths.pkl', 'wb'))
+    ad3 = axtrack_amd.AxonDetections(model, tl, P, str(tmp_path))
+    ad3.detect_dataset()
+    ad3.assign_ids(astar_paths_cache='from')
+    Dm = {k: v.copy() for k, v in dists.items()}
+    Dm[lbl][i, j] = 500
+    dets = [(ad._host_dets()[1][t, :cnt[t]], x[t, :cnt[t]], y[t, :cnt[t]]) for t in range(len(cnt))]
+    trajs, total = orc.mcf_solve(dets, Dm, orc.DEFAULTS, 'cachetest')
+    got = tracks_from_next(np.zeros(len(ad3._track_flat)), ad3._track_flat, ad3._offs)
+    assert got == trajs and ad3.mcf_total_cost == total
+
+
 # ----------------------------------------------------------------------------------------- f-3 (next row)
 def test_box_histograms_bit_exact_against_oracle():
     """feature_model on the GPU: boxes in the interior, on every edge and corner, partly and completely outside the
