@@ -10,7 +10,7 @@ def short(name):
     m = re.search(r'conv3x3_s2_k1<(\d+), (\d+)', name)
     if m:
         return f'conv3x3_s2_k1<{m.group(1)}->{m.group(2)},s2>'
-    m = re.search(r'hungarian_pair_kernel<(\d)>', name)
+    m = re.search(r'hungarian_pair_kernel<(\d)(?:, (\d))?>', name)
     if m:
         return f'hungarian_pair_kernel<gap{m.group(1)}>'
     m = re.search(r'(\w+)(<|\()', name.replace('(anonymous namespace)::', '').replace('void ', ''))
