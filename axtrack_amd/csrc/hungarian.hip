@@ -72,7 +72,7 @@ __device__ __forceinline__ void wave_argmin(long &key, int &idx)
 //   GAP == 1: writes succ1[t*cap+i] = j or -1 and pred1[(t+1)*cap+j] = i or -1 for every slot of the pair.
 //   GAP == 2: rows = detections of t with succ1 < 0, columns = detections of t+2 with pred1 < 0;
 //             writes succ2 / pred2 the same way.
-// NC > 0: frames with at most 64*NC detections -- the per-column search state (dual, distance, predecessor, matched
+// NC > 0 (3 or 9): frames with at most 64*NC detection slots -- the per-column search state (dual, distance, predecessor, matched
 // row, flags) lives in NC registers per lane instead of LDS, so that one search step costs one LDS round trip (the
 // cost row and the row dual) instead of a dozen dependent ones. NC == 0: any cap, column state in LDS.
 template <int GAP, int NC>
@@ -471,20 +471,22 @@ extern "C" int axt_hungarian_pairs(const int32_t *d_x, const int32_t *d_y, const
         AXT_CHECK_HIP(hipFuncSetAttribute((const void *)hungarian_pair_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         AXT_CHECK_HIP(hipFuncSetAttribute((const void *)hungarian_pair_kernel<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         AXT_CHECK_HIP(hipFuncSetAttribute((const void *)hungarian_pair_kernel<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        AXT_CHECK_HIP(hipFuncSetAttribute((const void *)hungarian_pair_kernel<1, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        AXT_CHECK_HIP(hipFuncSetAttribute((const void *)hungarian_pair_kernel<2, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         AXT_CHECK_HIP(hipFuncSetAttribute((const void *)hungarian_pair_kernel<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
     // pass 2 of source frame t needs pass 1 of the pairs (t, t+1) and (t+1, t+2): pass 1 runs one frame further
     const int e1 = (max_gap == 2 ? t_end + 1 : t_end) < n_frames - 1 ? (max_gap == 2 ? t_end + 1 : t_end) : n_frames - 1;
     if (e1 > t_begin) {
-        hipLaunchKernelGGL((cap <= 192 ? hungarian_pair_kernel<1, 3> : hungarian_pair_kernel<1, 0>), dim3(e1 - t_begin), dim3(64), lds, st, d_x, d_y, d_count, frame_off,
+        hipLaunchKernelGGL((cap <= 192 ? hungarian_pair_kernel<1, 3> : cap <= 576 ? hungarian_pair_kernel<1, 9> : hungarian_pair_kernel<1, 0>), dim3(e1 - t_begin), dim3(64), lds, st, d_x, d_y, d_count, frame_off,
                            n_frames, cap, H, W, max_dist, conn8, h_dmax[0], (const long *)d_cost_units, (long)thr_units,
                            (const int *)nullptr, (const int *)nullptr, succ1, pred1, cdim, t_begin);
         AXT_LAUNCH_CHECK();
     }
     const int e2 = t_end < n_frames - 2 ? t_end : n_frames - 2;
     if (max_gap == 2 && e2 > t_begin) {
-        hipLaunchKernelGGL((cap <= 192 ? hungarian_pair_kernel<2, 3> : hungarian_pair_kernel<2, 0>), dim3(e2 - t_begin), dim3(64), lds, st, d_x, d_y, d_count, frame_off,
+        hipLaunchKernelGGL((cap <= 192 ? hungarian_pair_kernel<2, 3> : cap <= 576 ? hungarian_pair_kernel<2, 9> : hungarian_pair_kernel<2, 0>), dim3(e2 - t_begin), dim3(64), lds, st, d_x, d_y, d_count, frame_off,
                            n_frames, cap, H, W, max_dist, conn8, h_dmax[1],
                            (const long *)d_cost_units + (max_dist + 1), (long)thr_units, (const int *)succ1,
                            (const int *)pred1, succ2, pred2, cdim, t_begin);

@@ -328,17 +328,18 @@ def test_hungarian_association_random_frames(seed):
 
 
 def test_hungarian_association_wide_and_long():
-    """cap = 576 (four tiles) x 130 frames: more than 192 detection slots per frame (search state in LDS instead of
-    registers) and more than 8 k slots (chain numbering by multi-launch pointer doubling instead of one workgroup)."""
+    """cap = 576 (four tiles) and 720 x 130 frames: more than 192 detection slots per frame (search state in nine
+    registers per lane, or in LDS beyond 576 slots) and more than 8 k slots (chain numbering by multi-launch pointer doubling instead of one workgroup)."""
     rng = np.random.default_rng(77)
     dets = []
     for t in range(130):
         n = int(rng.integers(0, 14)) if t % 17 else 230          # mostly sparse, a few crowded frames (> 192)
         conf = np.sort(rng.uniform(0.55, 1.2, n).astype(np.float32))[::-1]
         dets.append((conf, rng.integers(0, 1024, n), rng.integers(0, 1024, n)))
-    got, n = _hungarian_tracks(dets, 1024, 1024, cap=576)
     ref = orc.hungarian_assoc(dets, 1024, 1024)
-    assert n == len(ref) and got == ref
+    for cap in (576, 720):                   # 9 register slots per lane / column state in LDS
+        got, n = _hungarian_tracks(dets, 1024, 1024, cap=cap)
+        assert n == len(ref) and got == ref, cap
 
 
 def test_inference_hungarian_mode_end_to_end(weights):
