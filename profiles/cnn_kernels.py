@@ -17,4 +17,4 @@ for _ in range(R):
 torch.cuda.synchronize()
 prof = model.read_profile()
 tot = sum(k['ms'] for k in prof) / R
-print(os.environ.get('AXT_DBG', '-'), ' '.join(f"{k['name'].split()[0]}={k['ms'] / R:.3f}" for k in prof[:9]), f'total={tot:.3f}')
+print(' '.join(f"{k['name'].split()[0]}={k['ms'] / R:.3f}" for k in prof[:9]), f'total={tot:.3f}')
