@@ -5,9 +5,11 @@
 //                    MaxPool2d(2,2)) for conv blocks 2..10: the input patch and a K-chunk of the weights are staged
 //                    in LDS, v_mfma_f32_16x16x4_f32 accumulates 16 pixels x 16 channels per instruction, the next
 //                    chunk's global loads are prefetched into registers behind the MFMAs.
-//   conv3x3_s2_mfma  the two stride-2 blocks: persistent workgroups, every wave its own barrier-free pipeline,
-//                    weights LDS-resident. Block 0 reads the 5-frame temporal stack straight from the timelapse
-//                    (fuses Timelapse.get_frametiles_stack, Timelapse.py:111-125,150-157).
+//   conv3x3_s2_k1    the two stride-2 blocks (HBM-bound) on v_mfma_f32_4x4x1_16b_f32: persistent workgroups, every
+//                    wave its own barrier-free pipeline over a wave-private LDS patch, weights LDS-resident, global
+//                    traffic through buffer loads / stores (zero padding from the range check). Block 0 reads the
+//                    5-frame temporal stack straight from the timelapse (fuses Timelapse.get_frametiles_stack,
+//                    Timelapse.py:111-125,150-157).
 //   gemm_mfma        split-K GEMM for the three linear layers, partial slabs reduced in a fixed order
 //                    (bit-reproducible) by reduce_bias_act (+ Sigmoid).
 //

@@ -3,9 +3,10 @@ the HIP hot path. Same public surface on the inference path -- detect_dataset(),
 get_frame_dets(), IDed_dets_all, _detections, dir, name, len() -- but a timelapse is processed as
 whole-array GPU passes instead of a Python loop over frames and DataFrames:
 
-    detect_dataset : tile occupancy -> CNN forward for all (frame, tile) -> decode+stitch+NMS
-    assign_ids     : observation costs + admissible-arc list on the GPU -> min-cost-flow solve
-                     -> trajectories -> IDed_dets_all
+    detect_dataset : CNN forward for all (frame, kept tile) -> decode+stitch+NMS
+    assign_ids     : observation costs + admissible-arc list on the GPU -> min-cost-flow solve (or the
+                     frame-to-frame Hungarian variant) -> trajectories -> IDed_dets_all (filled on the GPU)
+    compute_TP_FP_FN / get_detection_metrics : the evaluation metrics of labelled data, one launch
 
 pandas objects are only materialised at the API boundary (lazily for the per-frame tables).
 """
