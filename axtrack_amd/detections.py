@@ -511,6 +511,9 @@ class AxonDetections(object):
         frames x ids, so it is filled on the GPU (axt_ided_table) and copied once into pinned host memory,
         which the DataFrame then wraps without another copy."""
         track = self._track_dev()                                   # i32 [F,cap], -1 = no ID / empty slot
+        shard = getattr(self, '_shard', None)
+        if shard is not None:
+            return self._ided_block(track, shard[0], shard[1])
         n_ids, ids, id_row = self.n_ids, None, None
         if n_ids is None:                                           # adopted from a cache: ids may have gaps
             uniq = torch.unique(track[track >= 0])
@@ -522,6 +525,22 @@ class AxonDetections(object):
                              id_row, None if ids is None else len(ids))
         return pd.DataFrame(vals, index=_axon_index(np.arange(n_ids) if ids is None else ids),
                             columns=_ided_columns(len(self)), copy=False)
+
+    def _ided_block(self, track, a, b):
+        """Frame-sharded runs: the dense table of a timelapse grows with frames x identities, so every rank
+        materialises only its own frames [a, b) of it -- the identities alive there (rows) x those frames (columns,
+        labelled with their true frame index, no label quirk yet). sharded.assemble_ided_dets_all() joins the blocks
+        into exactly the table a single process builds (quirk included); the work and the PCIe traffic per rank stay
+        constant as ranks are added."""
+        tr = track[a:b]
+        alive = torch.unique(tr[tr >= 0])
+        id_row = torch.full((max(int(self.n_ids or 0), 1),), -1, dtype=torch.int32, device=self.device)
+        id_row[alive.long()] = torch.arange(len(alive), dtype=torch.int32, device=self.device)
+        vals = hp.ided_table(tr, self.d_conf[a:b], self.d_x[a:b], self.d_y[a:b], self.d_count[a:b], int(self.n_ids or 0),
+                             False, id_row, len(alive))
+        cols = pd.MultiIndex.from_product([range(a, b), ['anchor_x', 'anchor_y', 'conf']], names=('frameID', 'detInfo'))
+        self.IDed_dets_block = (a, b)
+        return pd.DataFrame(vals, index=_axon_index(alive.cpu().numpy()), columns=cols, copy=False)
 
     def _track_dev(self):
         """Trajectory id of every detection slot on the device, i32 [F,cap] (-1: none)."""

@@ -33,3 +33,39 @@ def all_gather_detections(conf, x, y, count, group=None):
     g_y = out[:, 2 * cap:3 * cap].contiguous()
     g_count = out[:, 3 * cap].contiguous()
     return g_conf, g_x, g_y, g_count
+
+
+def assemble_ided_dets_all(blocks, n_frames, reproduce_label_quirk=True):
+    """Join the per-rank blocks of IDed_dets_all (AxonDetections._ided_block: rows = identities alive in the rank's
+    frames, columns = those frames) into the table of the whole timelapse, exactly as a single process builds it
+    (AxonDetections.py:825-842): identities ascending, and -- by default -- the reference's label quirk: frames
+    without any IDed detection drop out of the concat, the rest are labelled by position, NaN columns fill the end."""
+    import numpy as np
+    import pandas as pd
+    from .detections import _axon_index, _ided_columns
+    blocks = sorted(blocks, key=lambda b: b.columns[0][0] if len(b.columns) else 0)
+    ids = sorted({int(name[5:]) for b in blocks for name in b.index})
+    row = {i: n for n, i in enumerate(ids)}
+    vals = np.full((len(ids), 3 * n_frames), np.nan)
+    pos = 0
+    for b in blocks:
+        v = b.to_numpy()
+        rows = np.array([row[int(name[5:])] for name in b.index], np.int64)
+        for k in range(v.shape[1] // 3):
+            trip = v[:, 3 * k:3 * k + 3]
+            if reproduce_label_quirk and np.isnan(trip).all():
+                continue                                  # a frame without IDed detections vanishes (:831)
+            col = 3 * pos if reproduce_label_quirk else 3 * int(b.columns[3 * k][0])
+            if len(rows):
+                vals[rows, col:col + 3] = trip
+            pos += 1
+    return pd.DataFrame(vals, index=_axon_index(np.array(ids, np.int64)), columns=_ided_columns(n_frames), copy=False)
+
+
+def gather_ided_dets_all(ad, group=None):
+    """All ranks: the table of the whole timelapse from every rank's block (one all_gather_object; on demand --
+    the hot path itself leaves each rank with its own block)."""
+    world = dist.get_world_size(group)
+    blocks = [None] * world
+    dist.all_gather_object(blocks, ad.IDed_dets_all, group=group)
+    return assemble_ided_dets_all(blocks, len(ad), ad.reproduce_label_quirk)

@@ -11,8 +11,9 @@ over a synthetic 512x512 timelapse that is already resident in HBM. Default work
 config "c3" (512x512x256, detection + association); "c2" is detection only.
 
 Multi-GPU (weak scaling): the timelapse has N x 252 detection frames, rank r detects its own
-contiguous block (reading a 2-frame halo), ONE all-gather of the detection lists over RCCL, then
-every rank runs the same deterministic global solve (replicated).
+contiguous block (reading a 2-frame halo), ONE all-gather of the detection lists over RCCL, then the
+association (Hungarian: every rank its own frame pairs + one MAX all-reduce; min-cost flow: replicated), and
+every rank materialises its own block of IDed_dets_all (its frames x the identities alive in them).
 
 Prints ONE JSON line on rank 0 (contract: see the task description), with
   roofline     -- dominant kernel: algorithmic FLOPs / HIP-event time measured inside the timed

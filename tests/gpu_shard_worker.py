@@ -28,7 +28,10 @@ def run(rank, world, port, q, total_frames, seed):
         ad.detect_dataset()
         ad.gather_detections()
         ad.assign_ids()
-        out[mode] = (ad.n_ids, ad._track_flat.tobytes(), ad.IDed_dets_all.to_numpy().tobytes())
+        block = ad.IDed_dets_all                                  # this rank's frames x the identities alive in them
+        assert ad.IDed_dets_block == (f0, f0 + per) and [c[0] for c in block.columns[::3]] == list(range(f0, f0 + per))
+        whole = sharded.gather_ided_dets_all(ad)
+        out[mode] = (ad.n_ids, ad._track_flat.tobytes(), whole.to_numpy().tobytes(), list(whole.index), block.shape)
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()

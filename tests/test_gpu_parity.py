@@ -429,8 +429,11 @@ def test_two_rank_frame_sharding(weights):
         P = params.load_parameters()
         P['ASSOCIATION'] = mode
         ad = _run_inference(frames, weights, P, name='shard')
-        ref = (ad.n_ids, ad._track_flat.tobytes(), ad.IDed_dets_all.to_numpy().tobytes())
-        assert res[0][mode] == ref and res[1][mode] == ref, mode
+        ref = (ad.n_ids, ad._track_flat.tobytes(), ad.IDed_dets_all.to_numpy().tobytes(), list(ad.IDed_dets_all.index))
+        for r in (0, 1):
+            assert res[r][mode][:4] == ref, mode          # the table assembled from the two blocks is the global one
+            rows, cols = res[r][mode][4]
+            assert cols == 3 * (total // 2) and rows <= ad.n_ids
 
 
 # ----------------------------------------------------------------------------------------- f-2 (next row)

@@ -178,3 +178,31 @@ def test_flow_solver_fast_and_general_paths_agree_at_full_size(monkeypatch):
     monkeypatch.delenv('AXT_MCF_FORCE_SSP')
     capped = hp.mcf_solve(obs_i, en_i, ex_i, row_ptr, b, cost, 5, 40)
     assert capped[2] == 40 and capped[3] > fast[3]
+
+
+def test_sharded_ided_blocks_assemble_to_the_global_table():
+    """Frame-sharded runs leave every rank with its block of IDed_dets_all (its frames x the identities alive there);
+    sharded.assemble_ided_dets_all must rebuild the single-process table, label quirk included (a frame without
+    any IDed detection in the middle of rank 1's block, an identity that lives on both ranks, one that does not)."""
+    import pandas as pd
+    from axtrack_amd import sharded
+    from axtrack_amd.detections import _axon_index
+    F = 8
+    # per frame: list of (id, conf, x, y)
+    tables = [[(0, .9, 10, 11), (1, .8, 20, 21)], [(0, .7, 12, 13)], [(1, .6, 22, 23), (2, .95, 30, 31)], [(2, .9, 32, 33)],
+              [(2, .85, 34, 35), (3, .75, 40, 41)], [], [(3, .7, 42, 43)], [(3, .65, 44, 45), (4, .99, 50, 51)]]
+    for quirk in (True, False):
+        ids, labels, info, ref = orc.ided_dets_all(tables, reproduce_label_quirk=quirk)
+        blocks = []
+        for a, b in ((0, 4), (4, 8)):
+            alive = sorted({r[0] for f in range(a, b) for r in tables[f]})
+            v = np.full((len(alive), 3 * (b - a)), np.nan)
+            for f in range(a, b):
+                for tid, c, x, y in tables[f]:
+                    v[alive.index(tid), 3 * (f - a):3 * (f - a) + 3] = (x, y, c)
+            cols = pd.MultiIndex.from_product([range(a, b), ['anchor_x', 'anchor_y', 'conf']])
+            blocks.append(pd.DataFrame(v, index=_axon_index(np.array(alive)), columns=cols))
+        whole = sharded.assemble_ided_dets_all(blocks[::-1], F, quirk)          # order of arrival must not matter
+        assert list(whole.index) == [f'Axon_{i:0>3}' for i in ids]
+        assert np.array_equal(np.nan_to_num(whole.to_numpy(), nan=-1), np.nan_to_num(ref, nan=-1))
+        assert [c[0] for c in whole.columns] == list(labels.astype(int))
