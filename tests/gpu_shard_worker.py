@@ -21,9 +21,11 @@ def run(rank, world, port, q, total_frames, seed):
     model = axtrack_amd.Detector(synth.synth_state_dict(42), max_batch=per)
     tl = axtrack_amd.Timelapse(frames, name='shard')
     out = {}
-    for mode in ('hungarian', 'mcf'):
+    for mode in ('hungarian', 'mcf', 'mcf+appearance'):
         P = params.load_parameters()
-        P['ASSOCIATION'] = mode
+        P['ASSOCIATION'] = mode.split('+')[0]
+        if '+' in mode:
+            P['MCF_VIS_SIM_WEIGHT'] = 0.2          # the histograms need the pixels: they travel with the detections
         ad = axtrack_amd.AxonDetections(model, tl, P, None)
         ad.detect_dataset()
         ad.gather_detections()

@@ -425,9 +425,11 @@ def test_two_rank_frame_sharding(weights):
         p.join(timeout=60)
         assert p.exitcode == 0
     frames = synth.synth_frames(total + 4, 512, 512, seed=seed)
-    for mode in ('hungarian', 'mcf'):
+    for mode in ('hungarian', 'mcf', 'mcf+appearance'):
         P = params.load_parameters()
-        P['ASSOCIATION'] = mode
+        P['ASSOCIATION'] = mode.split('+')[0]
+        if '+' in mode:
+            P['MCF_VIS_SIM_WEIGHT'] = 0.2
         ad = _run_inference(frames, weights, P, name='shard')
         ref = (ad.n_ids, ad._track_flat.tobytes(), ad.IDed_dets_all.to_numpy().tobytes(), list(ad.IDed_dets_all.index))
         for r in (0, 1):
