@@ -640,6 +640,92 @@ __global__ __launch_bounds__(256) void gemm_mfma(const float *__restrict__ A, in
             }
 }
 
+// The same GEMM with a 128 x 128 block tile (wave tile 64 x 64 = 4 x 4 MFMA tiles) for the first linear layer, whose
+// 168 MB of weights and 41 MB of activations are each streamed once per block row / column: a 64 x 64 tile reads the
+// weights 4 times and the activations 16 times (1.3 GB), this one 2 and 8 times.
+constexpr int HBM_ = 128, HBN = 128, HLDA = 34, HLDB = 144;
+
+__global__ __launch_bounds__(256) void gemm_mfma_128(const float *__restrict__ A, int lda, const float *__restrict__ Bm, int N,
+                                                     float *__restrict__ slab, int M, int kper)
+{
+    __shared__ __attribute__((aligned(16))) float As[HBM_ * HLDA];
+    __shared__ __attribute__((aligned(16))) float Bs[GBK * HLDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 15, q = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n0 = blockIdx.x * HBN, m0 = blockIdx.y * HBM_;
+    const int k0 = blockIdx.z * kper;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // staging: A tile 128 rows x 32 k as float2 (2048 -> 8 per thread), B tile 32 k x 128 n as float4 (1024 -> 4)
+    float2 av[8];
+    f32x4 bv[4];
+    const float *ap[8];
+    const float *bp[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int e = tid + i * 256;
+        int gm = m0 + (e >> 4);
+        gm = gm < M ? gm : M - 1;
+        ap[i] = A + (long)gm * lda + (e & 15) * 2;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + i * 256;
+        bp[i] = Bm + (long)(e >> 5) * N + n0 + (e & 31) * 4;
+    }
+    auto load_tile = [&](int k) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) av[i] = *reinterpret_cast<const float2 *>(ap[i] + k);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const f32x4 *>(bp[i] + (long)k * N);
+    };
+    load_tile(k0);
+    for (int k = k0; k < k0 + kper; k += GBK) {
+        if (k != k0) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = tid + i * 256;
+            *reinterpret_cast<float2 *>(&As[(e >> 4) * HLDA + (e & 15) * 2]) = av[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + i * 256;
+            *reinterpret_cast<f32x4 *>(&Bs[(e >> 5) * HLDB + (e & 31) * 4]) = bv[i];
+        }
+        __syncthreads();
+        if (k + GBK < k0 + kper) load_tile(k + GBK);
+#pragma unroll
+        for (int s = 0; s < GBK / 4; ++s) {
+            float a[4], bw[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = As[(wm * 64 + i * 16 + p) * HLDA + s * 4 + q];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bw[j] = Bs[(s * 4 + q) * HLDB + wn * 64 + j * 16 + p];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bw[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    float *dst = slab + (long)blockIdx.z * M * N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 64 + i * 16 + q * 4 + r, n = n0 + wn * 64 + j * 16 + p;
+                if (m < M) dst[(long)m * N + n] = acc[i][j][r];
+            }
+}
+
 // out[m][n] = act(bias[n] + sum_z slab[z][m][n]), n < Nout (slab rows are N wide), fixed z order
 __global__ void reduce_bias_act(const float *__restrict__ slab, int S, int M, int N, int Nout,
                                 const float *__restrict__ bias, int sigmoid, float *__restrict__ out)
@@ -666,7 +752,7 @@ static const ConvPlan kPlan[8] = {{5, 2, 1}, {4, 3, 1}, {8, 5, 1}, {8, 5, 1}, {8
 // the Infinity Cache. 128 items of block-0 output are 0.67 GB.
 constexpr int kChunkA = 128;      // conv blocks 0-2
 constexpr int kChunkB = 128;      // conv blocks 3-4
-constexpr int kFc1Split = 8, kFc2Split = 4, kFc3Split = 4;
+constexpr int kFc1Split = 32, kFc2Split = 4, kFc3Split = 4;
 
 }  // namespace
 
@@ -835,6 +921,12 @@ int launch_gemm(const float *A, int lda, const float *Bm, int N, float *slab, in
                 hipStream_t st)
 {
     AXT_REQUIRE(N % GBN == 0 && K % (split * GBK) == 0, "gemm: bad shape N=%d K=%d split=%d", N, K, split);
+    if (N % HBN == 0 && M > GBM && K >= 8192) {          // the first linear layer at batch sizes beyond one 64-row tile
+        dim3 grid(N / HBN, axt_cdiv(M, HBM_), split);
+        hipLaunchKernelGGL(gemm_mfma_128, grid, dim3(256), 0, st, A, lda, Bm, N, slab, M, K / split);
+        AXT_LAUNCH_CHECK();
+        return AXT_OK;
+    }
     dim3 grid(N / GBN, axt_cdiv(M, GBM), split);
     hipLaunchKernelGGL(gemm_mfma, grid, dim3(256), 0, st, A, lda, Bm, N, slab, M, K / split);
     AXT_LAUNCH_CHECK();
