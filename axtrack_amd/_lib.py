@@ -35,6 +35,8 @@ SIGNATURES = {
     'axt_obs_costs': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p]),
     'axt_path_cost': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                               c_int, c_void_p, c_void_p]),
+    'axt_path_cells': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
+                               c_int, c_void_p, c_void_p, c_void_p]),
     'axt_build_arcs': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_void_p, ctypes.POINTER(c_int64), c_void_p]),

@@ -17,7 +17,7 @@
 
 int axt_path_cost_masked(const int32_t *d_xa, const int32_t *d_ya, int na, const int32_t *d_xb, const int32_t *d_yb,
                          int nb, const uint8_t *d_mask, int H, int W, int max_dist, int conn8, int32_t *d_D,
-                         hipStream_t st);
+                         hipStream_t st, int32_t *d_cells);
 struct axt_grid;
 extern "C" const uint8_t *axt_grid_mask(const axt_grid *g);
 int axt_masked_distance_table(const axt_grid *g, const int32_t *d_x, const int32_t *d_y, const int32_t *d_count,
@@ -278,12 +278,23 @@ int axt_path_cost(const int32_t *d_xa, const int32_t *d_ya, int na, const int32_
     if ((long)na * nb == 0) return AXT_OK;
     AXT_REQUIRE(d_xa && d_ya && d_xb && d_yb && d_D, "null argument");
     hipStream_t st = (hipStream_t)stream;
-    if (grid) return axt_path_cost_masked(d_xa, d_ya, na, d_xb, d_yb, nb, axt_grid_mask(grid), H, W, max_dist, conn8, d_D, st);
+    if (grid) return axt_path_cost_masked(d_xa, d_ya, na, d_xb, d_yb, nb, axt_grid_mask(grid), H, W, max_dist, conn8, d_D, st, nullptr);
     const long n = (long)na * nb;
     hipLaunchKernelGGL(path_cost_open_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_xa, d_ya, na, d_xb,
                        d_yb, nb, H, W, max_dist, conn8, d_D);
     AXT_LAUNCH_CHECK();
     return AXT_OK;
+}
+
+int axt_path_cells(const int32_t *d_xa, const int32_t *d_ya, int na, const int32_t *d_xb, const int32_t *d_yb, int nb,
+                   const axt_grid *grid, int H, int W, int max_dist, int conn8, int32_t *d_D, int32_t *d_cells, void *stream)
+{
+    AXT_REQUIRE(na >= 0 && nb >= 0 && H > 0 && W > 0 && max_dist > 0 && max_dist < 32768, "bad argument");
+    AXT_REQUIRE(grid, "axt_path_cells: needs a masked grid (on an all-ones mask every monotone staircase is a shortest path)");
+    if ((long)na * nb == 0) return AXT_OK;
+    AXT_REQUIRE(d_xa && d_ya && d_xb && d_yb && d_D && d_cells, "null argument");
+    return axt_path_cost_masked(d_xa, d_ya, na, d_xb, d_yb, nb, axt_grid_mask(grid), H, W, max_dist, conn8, d_D,
+                                (hipStream_t)stream, d_cells);
 }
 
 static int build_arcs_impl(const int32_t *d_x, const int32_t *d_y, const int32_t *d_count, int n_frames, int cap,

@@ -112,11 +112,50 @@ __global__ __launch_bounds__(256) void path_sssp_kernel(
     }
 }
 
+// The cells of the paths whose lengths the search above found: walk from the target back to the source, at every
+// cell c to the first neighbour n (order: up, down, left, right, then the diagonals) with key[n] + weight(c) == key[c]
+// -- one exists at the fixed point of the search. cells[(src*nb + j)*max_dist + k] = y*W + x of the k-th cell, source
+// first, for k < D[src][j]; pairs without a path (D == max_dist) are left alone. Which of several equally cheap
+// paths the reference's A* returns is not pinned: this is one of them.
+__global__ __launch_bounds__(64) void path_backtrack_kernel(
+    const int *__restrict__ xb, const int *__restrict__ yb, int nb, const unsigned char *__restrict__ mask, int H, int W,
+    int max_dist, int conn8, long win_cells_cap, const u64 *__restrict__ key_base, const int *__restrict__ D,
+    int *__restrict__ cells)
+{
+    const int src = blockIdx.y, j = blockIdx.x * 64 + threadIdx.x;
+    if (j >= nb) return;
+    const int d = D[(long)src * nb + j];
+    if (d >= max_dist) return;
+    const u64 *key = key_base + (long)src * win_cells_cap;
+    int *out = cells + ((long)src * nb + j) * max_dist;
+    const int nn = conn8 ? 8 : 4;
+    const int dy8[8] = {-1, 1, 0, 0, -1, -1, 1, 1}, dx8[8] = {0, 0, -1, 1, -1, 1, -1, 1};
+    int cx = xb[j], cy = yb[j];
+    for (int k = d - 1; k >= 0; --k) {
+        const long c = (long)cy * W + cx;
+        out[k] = (int)c;
+        if (k == 0) break;
+        const u64 want = key[c] - (1ull + (mask[c] == 1 ? 0ull : (1ull << 32)));
+        int found = -1;
+        for (int q = 0; q < nn && found < 0; ++q) {
+            const int ny = cy + dy8[q], nx = cx + dx8[q];
+            if (ny < 0 || ny >= H || nx < 0 || nx >= W) continue;
+            if (key[(long)ny * W + nx] == want) found = q;
+        }
+        if (found < 0) {                                   // cannot happen at the fixed point; leave a visible mark
+            for (int r = 0; r < k; ++r) out[r] = -1;
+            break;
+        }
+        cy += dy8[found];
+        cx += dx8[found];
+    }
+}
+
 }  // namespace
 
 int axt_path_cost_masked(const int32_t *d_xa, const int32_t *d_ya, int na, const int32_t *d_xb, const int32_t *d_yb,
                          int nb, const uint8_t *d_mask, int H, int W, int max_dist, int conn8, int32_t *d_D,
-                         hipStream_t st)
+                         hipStream_t st, int32_t *d_cells)
 {
     const long win = (long)H * W;
     // sources are processed in batches so that the HBM scratch (24 bytes per window cell and source) stays bounded
@@ -136,6 +175,11 @@ int axt_path_cost_masked(const int32_t *d_xa, const int32_t *d_ya, int na, const
         hipLaunchKernelGGL(path_sssp_kernel, dim3(n), dim3(256), 0, st, d_xa + s0, d_ya + s0, n, d_xb, d_yb, nb, d_mask, H,
                            W, max_dist, conn8, win, sc, d_D + s0 * nb);
         AXT_LAUNCH_CHECK();
+        if (d_cells) {
+            hipLaunchKernelGGL(path_backtrack_kernel, dim3((nb + 63) / 64, n), dim3(64), 0, st, d_xb, d_yb, nb, d_mask, H, W,
+                               max_dist, conn8, win, (const u64 *)sc.key, (const int *)(d_D + s0 * nb), d_cells + s0 * nb * max_dist);
+            AXT_LAUNCH_CHECK();
+        }
     }
     AXT_CHECK_HIP(hipFreeAsync(raw, st));
     return AXT_OK;
@@ -444,7 +488,7 @@ int axt_masked_distance_table(const axt_grid *g, const int32_t *d_x, const int32
                     const int nb = hc[tb] < cap ? hc[tb] : cap;
                     if (nb == 0) continue;
                     int rc = axt_path_cost_masked(d_x + (size_t)t * cap + i, d_y + (size_t)t * cap + i, 1, d_x + (size_t)tb * cap,
-                                                  d_y + (size_t)tb * cap, nb, g->d_mask, g->H, g->W, max_dist, g->conn8, dex, st);
+                                                  d_y + (size_t)tb * cap, nb, g->d_mask, g->H, g->W, max_dist, g->conn8, dex, st, nullptr);
                     if (rc) { (void)hipFree(dex); return rc; }
                     hipLaunchKernelGGL(mask_patch_kernel, dim3((nb + 255) / 256), dim3(256), 0, st,
                                        d_Dtmp + (((size_t)t * cap + i) * max_gap + gp) * cap, (const int *)dex, nb, h_dmax[gp]);

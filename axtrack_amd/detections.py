@@ -272,7 +272,7 @@ class AxonDetections(object):
     def assign_ids(self, astar_paths_cache=None, assigedIDs_cache=None):
         """AxonDetections.py:505-524. astar_paths_cache: 'from' adopts the path lengths of a
         '{name}_astar_dets_paths.pkl' (the reference's format: per frame pair a nested list of coo matrices / None)
-        instead of computing them; 'to' writes such a file (all-ones masks only: see astar_dets_paths)."""
+        instead of computing them; 'to' writes such a file (astar_dets_paths)."""
         self._len_table = None
         if assigedIDs_cache != 'from':
             if astar_paths_cache == 'from':
@@ -373,12 +373,13 @@ class AxonDetections(object):
         marking the cells of a shortest path, or None beyond max_px_assoc_dist. On an all-ones mask every monotone
         staircase between the two anchors is a shortest path; this one walks the columns first, then the rows (which
         of the equally short paths pyastar2d returns is unpinned; lengths are what the tracker
-        uses). Masked grids: not materialised (the GPU search keeps distances, not predecessors)."""
+        uses). On a masked grid the GPU search walks back from every target along its distance field
+        (axt_path_cells)."""
         from scipy import sparse
         if self.dataset.mask2d is not None:
-            raise NotImplementedError('paths on a masked grid are not materialised; their lengths are (astar_dists)')
+            return self._masked_dets_paths()
         if self.conn8:
-            raise NotImplementedError('path materialisation is implemented for the 4-connected grid')
+            raise NotImplementedError('staircase materialisation is implemented for the 4-connected grid')
         dists = self.astar_dists()
         cnt, _, x, y = self._host_dets()
         H, W = self.dataset.sizey, self.dataset.sizex
@@ -400,6 +401,39 @@ class AxonDetections(object):
                     row.append(sparse.coo_matrix((np.ones(len(r)), (r, c)), (H, W), bool))
                 rows.append(row)
             out[lbl] = rows
+        return out
+
+    def _masked_dets_paths(self):
+        """astar_dets_paths on a masked grid: one exact single-source search per detection of t_bef, then the walk
+        back from every detection of t (hotpath.path_cells)."""
+        from scipy import sparse
+        cnt = self._host_dets()[0]
+        grid = self._mask_dev()
+        H, W = self.dataset.sizey, self.dataset.sizex
+        out = {}
+        for t in range(len(self)):
+            for t_bef in range(t - 1, t - (self.P['MCF_MAX_NUM_MISSES'] + 2), -1):
+                if t_bef < 0:
+                    continue
+                na, nb = int(cnt[t_bef]), int(cnt[t])
+                lbl = f'{self.dataset.name}_t:{t:0>3}-t:{t_bef:0>3}'
+                if na == 0 or nb == 0:
+                    out[lbl] = [[] for _ in range(na)]
+                    continue
+                D, cells = hp.path_cells(self.d_x[t_bef, :na], self.d_y[t_bef, :na], self.d_x[t, :nb], self.d_y[t, :nb],
+                                         H, W, grid, self.max_px_assoc_dist, self.conn8)
+                D, cells = D.cpu().numpy(), cells.cpu().numpy()
+                rows = []
+                for i in range(na):
+                    row = []
+                    for j in range(nb):
+                        if D[i, j] >= self.max_px_assoc_dist:
+                            row.append(None)
+                            continue
+                        c = cells[i, j, :D[i, j]]
+                        row.append(sparse.coo_matrix((np.ones(len(c)), (c // W, c % W)), (H, W), bool))
+                    rows.append(row)
+                out[lbl] = rows
         return out
 
     def _appearance(self):

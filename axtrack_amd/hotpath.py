@@ -224,6 +224,21 @@ def path_cost(xa, ya, xb, yb, H, W, mask=None, max_dist=MAX_PX_ASSOC_DIST, conn8
     return D
 
 
+def path_cells(xa, ya, xb, yb, H, W, mask, max_dist=MAX_PX_ASSOC_DIST, conn8=False):
+    """The A* paths of one frame pair on a masked grid (utils.py:379-387): (D i32 [na,nb], cells i32 [na,nb,max_dist]),
+    cells[i,j,:D[i,j]] = y*W + x along one minimum-cost path, source first, for the pairs with D < max_dist."""
+    na, nb = xa.numel(), xb.numel()
+    D = torch.empty((na, nb), dtype=torch.int32, device=xa.device)
+    cells = torch.full((na, nb, int(max_dist)), -1, dtype=torch.int32, device=xa.device)
+    if not isinstance(mask, Grid):
+        mask = Grid(mask.cpu().numpy() if isinstance(mask, torch.Tensor) else mask, conn8, xa.device)
+    with torch.cuda.device(xa.device):
+        _lib.check(_lib.load().axt_path_cells(xa.data_ptr(), ya.data_ptr(), na, xb.data_ptr(), yb.data_ptr(), nb, mask._h,
+                                              H, W, int(max_dist), int(bool(conn8)), D.data_ptr(), cells.data_ptr(),
+                                              _stream()), 'axt_path_cells')
+    return D, cells
+
+
 def box_histograms(frames, x, y, count, t_offset=2, box=AXON_BOX_SIZE):
     """feature_model (mincostflow_models.py:30-65) for every detection: (hist f32 [F,cap,180], bin sums f64 [F,cap]).
     frames f32 [T_all,H,W] on the GPU; detection frame f is shown frame f + t_offset (its centre frame)."""

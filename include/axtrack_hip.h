@@ -151,6 +151,16 @@ int axt_path_cost(const int32_t *d_xa, const int32_t *d_ya, int na,
                   const axt_grid *grid, int H, int W, int max_dist, int conn8,
                   int32_t *d_D, void *stream);
 
+/* The paths themselves (the coo matrices _compute_astar_path returns, utils.py:379-387; kept by
+ * _compute_detections_astar_paths, AxonDetections.py:570-577, for the cache file and for drawing): D as above, and
+ * d_cells i32 [na, nb, max_dist] receives, for every pair with D < max_dist, the D cells of one minimum-cost path
+ * as y*W + x, source first; other entries are left untouched. Needs a grid (all-ones masks have closed-form
+ * staircases); which of several equally cheap paths pyastar2d would return is not pinned. */
+int axt_path_cells(const int32_t *d_xa, const int32_t *d_ya, int na,
+                   const int32_t *d_xb, const int32_t *d_yb, int nb,
+                   const axt_grid *grid, int H, int W, int max_dist, int conn8,
+                   int32_t *d_D, int32_t *d_cells, void *stream);
+
 /* All admissible transition arcs of a timelapse in one pass (what transition_model,
  * mincostflow_models.py:67-119, and the tracker's cost_threshold keep): for every detection
  * a of frame t and b of frame t+g (g = 1..max_gap) with D(a,b) <= h_dmax[g-1], one arc a->b.

@@ -389,6 +389,91 @@ def test_path_cost_masked_grid_matches_oracle():
     assert np.array_equal(D1, D0)
 
 
+@pytest.mark.parametrize('conn8', [False, True])
+def test_path_cells_on_a_masked_grid_are_minimum_cost_paths(conn8):
+    """axt_path_cells: every materialised path starts at its source, ends at its target, moves between neighbouring
+    cells, has the oracle's number of cells, and costs (weight of every cell entered, {1 on mask, 65536 off}) exactly
+    what an independent Dijkstra (scipy.sparse.csgraph) finds."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import dijkstra
+    H, W = 96, 130
+    mask = synth.corridor_mask(H, W, width=10, pitch=34)
+    mask[40:52, :] = False
+    mask[44:47, 60:70] = True                                    # an island inside the gap
+    rng = np.random.default_rng(11)
+    na, nb = 9, 12
+    xa, ya = rng.integers(0, W, na), rng.integers(0, H, na)
+    xb, yb = rng.integers(0, W, nb), rng.integers(0, H, nb)
+    xb[3], yb[3] = xa[4], ya[4]                                  # a one-cell path
+    xa[0], ya[0] = W + 3, 5                                      # outside the grid: no paths
+    max_dist = 90                                                # some pairs are too far / too long
+    D, cells = hp.path_cells(dev(xa, torch.int32), dev(ya, torch.int32), dev(xb, torch.int32), dev(yb, torch.int32),
+                             H, W, dev(mask.astype(np.uint8)), max_dist, conn8)
+    D, cells = D.cpu().numpy(), cells.cpu().numpy()
+    ref = orc.path_matrix((None, xa, ya), (None, xb, yb), H, W, mask, max_dist, conn8)
+    assert np.array_equal(D, ref)
+    # the grid as a graph: an edge into cell c costs weight(c)
+    wgt = np.where(mask, 1.0, 65536.0)
+    idx = np.arange(H * W).reshape(H, W)
+    steps = [(-1, 0), (1, 0), (0, -1), (0, 1)] + ([(-1, -1), (-1, 1), (1, -1), (1, 1)] if conn8 else [])
+    src_n, dst_n, w_n = [], [], []
+    for dy, dx in steps:
+        ys, xs = np.mgrid[max(0, -dy):H - max(0, dy), max(0, -dx):W - max(0, dx)]
+        src_n.append(idx[ys, xs].ravel()); dst_n.append(idx[ys + dy, xs + dx].ravel()); w_n.append(wgt[ys + dy, xs + dx].ravel())
+    G = coo_matrix((np.concatenate(w_n), (np.concatenate(src_n), np.concatenate(dst_n))), (H * W, H * W)).tocsr()
+    checked = 0
+    for i in range(na):
+        if not (0 <= xa[i] < W and 0 <= ya[i] < H):
+            assert (D[i] == max_dist).all()
+            continue
+        best = dijkstra(G, indices=int(ya[i] * W + xa[i]))
+        for j in range(nb):
+            if D[i, j] >= max_dist:
+                assert (cells[i, j] == -1).all()
+                continue
+            c = cells[i, j, :D[i, j]]
+            assert (cells[i, j, D[i, j]:] == -1).all()
+            assert c[0] == ya[i] * W + xa[i] and c[-1] == yb[j] * W + xb[j]
+            r, q = c // W, c % W
+            dr, dq = np.abs(np.diff(r)), np.abs(np.diff(q))
+            assert np.all((np.maximum(dr, dq) == 1) if conn8 else (dr + dq == 1))
+            assert len(set(c.tolist())) == len(c)
+            assert wgt.ravel()[c[1:]].sum() == best[c[-1]]
+            checked += 1
+    assert checked > 30 and D[4, 3] == 1
+
+
+def test_path_cache_round_trip_on_a_masked_grid(weights, tmp_path):
+    """The path cache of a masked timelapse: written from axt_path_cells, its lengths are those the arc builder's own
+    search finds, and reading it back gives the same trajectories."""
+    import pickle
+    import axtrack_amd
+    frames = synth.synth_frames(7, 512, 512, seed=23)
+    mask = synth.corridor_mask(512, 512, width=40, pitch=128)
+    P = params.load_parameters()
+    model = axtrack_amd.Detector(weights, max_batch=8)
+    tl = axtrack_amd.Timelapse(frames, name='maskcache', mask=mask)
+    ad = axtrack_amd.AxonDetections(model, tl, P, str(tmp_path))
+    ad.detect_dataset()
+    ad.assign_ids()
+    ref_tracks, ref_cost = ad._track_flat.copy(), ad.mcf_total_cost
+    ad.assign_ids(astar_paths_cache='to')
+    assert np.array_equal(ad._track_flat, ref_tracks) and ad.mcf_total_cost == ref_cost
+    paths = pickle.load(open(tmp_path / 'maskcache_astar_dets_paths.pkl', 'rb'))
+    dists = ad.astar_dists()
+    n_paths = 0
+    for lbl, rows in paths.items():
+        for i, row in enumerate(rows):
+            for j, p in enumerate(row):
+                assert (dists[lbl][i, j] == 500) if p is None else (p.getnnz() == dists[lbl][i, j])
+                n_paths += p is not None
+    assert n_paths > 50
+    ad2 = axtrack_amd.AxonDetections(model, tl, P, str(tmp_path))
+    ad2.detect_dataset()
+    ad2.assign_ids(astar_paths_cache='from')
+    assert np.array_equal(ad2._track_flat, ref_tracks) and ad2.mcf_total_cost == ref_cost
+
+
 def test_inference_with_mask_end_to_end(weights):
     """512x512x7 with a corridor mask: the masked arc builder + flow solve equal the oracle's."""
     import axtrack_amd
