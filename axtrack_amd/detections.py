@@ -187,7 +187,7 @@ class AxonDetections(object):
             det = pd.DataFrame({'conf': pd.array(np.ones(len(gx), np.float32), dtype='Float32'),
                                 'anchor_x': pd.array(np.asarray(gx, np.int64), dtype='Int64'),
                                 'anchor_y': pd.array(np.asarray(gy, np.int64), dtype='Int64')},
-                               index=[f'Axon_{i:0>3}' for i in range(len(gx))])
+                               index=[f'Axon_{i:0>3}' for i in self._gt_ids[t]])
         else:
             raise NotImplementedError(f"which_dets={which_dets!r} is a plotting selection (out of scope)")
         if libmot:
@@ -207,11 +207,16 @@ class AxonDetections(object):
 
     # ------------------------------------------------------------------ detection metrics (AxonDetections.py:378-503)
     def set_groundtruth(self, labels):
-        """labels: per detection frame a pair (x, y) of integer anchor arrays. The reference reads them from the
-        labelled dataset's YOLO targets (get_frame_and_truedets, :355-376); the dataset side is out of scope here."""
+        """labels: per detection frame (x, y) or (x, y, ids) -- integer anchor arrays and, for the tracking scores of
+        search_MCF_params, the axons' identities (the numbers of the labels' Axon_### names; default: position in
+        the frame). The reference reads them from the labelled dataset's YOLO targets (get_frame_and_truedets,
+        :355-376); the dataset side is out of scope here."""
         if len(labels) != len(self):
             raise ValueError(f'{len(labels)} label frames for {len(self)} detection frames')
-        self._gt = [(np.asarray(x, np.int64), np.asarray(y, np.int64)) for x, y in labels]
+        self._gt = [(np.asarray(l[0], np.int64), np.asarray(l[1], np.int64)) for l in labels]
+        self._gt_ids = [np.asarray(l[2], np.int64) if len(l) > 2 else np.arange(len(l[0])) for l in labels]
+        if any(len(i) != len(x) or len(np.unique(i)) != len(i) for i, (x, _) in zip(self._gt_ids, self._gt)):
+            raise ValueError('label identities must be unique within a frame and match the anchors in number')
         gcap = max([len(x) for x, _ in self._gt] + [1])
         gx = np.zeros((len(self), gcap), np.int32); gy = np.zeros((len(self), gcap), np.int32)
         for t, (x, y) in enumerate(self._gt):
@@ -435,6 +440,41 @@ class AxonDetections(object):
                     rows.append(row)
                 out[lbl] = rows
         return out
+
+    def search_MCF_params(self, edge_cost_thr_values=(.4, .6, .7, .8, .9, 1, 1.2, 3),
+                          entry_exit_cost_values=(.2, .8, .9, 1, 1.1, 2), miss_rate_values=(0.9, 0.6),
+                          vis_sim_weight_values=(0, 0.1), conf_capping_method_values=('ceil', 'scale_to_max')):
+        """AxonDetections.py:845-922: re-solve the association for every combination of the five tracker parameters
+        (same nesting order) and score each against the labelled identities; one row per combination -- the five
+        parameters, then mot_metrics.MOTCHALLENGE_METRICS -- written to '{dir}/MCF_params_results.csv' and returned.
+        Every solve is the GPU arc build + flow solve of assign_ids (the detections and their appearance
+        histograms stay on the device between combinations); the parameters are restored afterwards."""
+        from . import mot_metrics
+        if not self.labelled:
+            raise ValueError("no labels: call set_groundtruth() first")
+        target = self.get_frame_dets('groundtruth', None, libmot=True)
+        names = ('edge_cost_thr', 'entry_exit_cost', 'miss_rate', 'vis_sim_weight', 'conf_capping_method')
+        keys = ('MCF_EDGE_COST_THR', 'MCF_ENTRY_EXIT_COST', 'MCF_MISS_RATE', 'MCF_VIS_SIM_WEIGHT', 'MCF_CONF_CAPPING_METHOD')
+        before = {k: self.P[k] for k in keys}
+        results = []
+        try:
+            for ec in edge_cost_thr_values:
+                for eec in entry_exit_cost_values:
+                    for mr in miss_rate_values:
+                        for vsw in vis_sim_weight_values:
+                            for ccm in conf_capping_method_values:
+                                self.P.update(dict(zip(keys, (ec, eec, mr, vsw, ccm))))
+                                self.assign_ids()
+                                pred = self.get_frame_dets('IDed', None, libmot=True) if self._solved else None
+                                ev = mot_metrics.compare_to_groundtruth(target, pred, float(self.nms_min_dist) ** 2)
+                                results.append(pd.concat([pd.Series((ec, eec, mr, vsw, ccm), names, dtype=object),
+                                                          mot_metrics.summarize(ev)]))
+        finally:
+            self.P.update(before)
+        results = pd.concat(results, axis=1).T
+        os.makedirs(self.dir, exist_ok=True)
+        results.to_csv(f'{self.dir}/MCF_params_results.csv')
+        return results
 
     def _appearance(self):
         """feature_model's histograms of every detection (device tensors hist f32 [F,cap,180], sums f64 [F,cap]),

@@ -845,3 +845,49 @@ def test_end_to_end_detections_against_oracle_cnn(weights):
         assert abs(len(mine) - len(theirs)) <= 1
     total = int(cnt.sum())
     assert exact >= 0.995 * total, f'only {exact}/{total} detections identical'
+
+
+def test_mcf_parameter_search_rows_match_the_oracle(golden, tmp_path):
+    """search_MCF_params (AxonDetections.py:845-922) over a small grid: every row's association is the oracle's
+    under those parameters (scored with the same tracking metrics), the combination that produced the labels scores
+    perfectly, the CSV has the reference's columns and the parameters are restored."""
+    import axtrack_amd, pandas as pd
+    from axtrack_amd import mot_metrics
+    from axtrack_amd.detections import AxonDetections
+    g = golden('detect_1024')
+    dets = golden_dets(g)
+    tl = axtrack_amd.Timelapse(np.zeros((len(dets) + 4, 1024, 1024), np.float32), name='synth')
+    P = params.load_parameters()
+    ad = AxonDetections(None, tl, P, str(tmp_path))
+    ad._set_detections_from_tables([pd.DataFrame({'conf': c, 'anchor_x': x, 'anchor_y': y}) for c, x, y in dets])
+    # labels = the association under the deployed parameters
+    ad.assign_ids()
+    frame, tid, _, x, y = ad.ided_arrays()
+    ad.set_groundtruth([(x[frame == t], y[frame == t], tid[frame == t]) for t in range(len(dets))])
+    grid = dict(edge_cost_thr_values=[0.4, P['MCF_EDGE_COST_THR']], entry_exit_cost_values=[0.9, P['MCF_ENTRY_EXIT_COST']],
+                miss_rate_values=[P['MCF_MISS_RATE']], vis_sim_weight_values=[0], conf_capping_method_values=['ceil', 'scale_to_max'])
+    res = ad.search_MCF_params(**grid)
+    assert ad.P == P
+    assert list(res.columns) == ['edge_cost_thr', 'entry_exit_cost', 'miss_rate', 'vis_sim_weight', 'conf_capping_method'] \
+        + mot_metrics.MOTCHALLENGE_METRICS
+    assert len(res) == 8
+    back = pd.read_csv(tmp_path / 'MCF_params_results.csv', index_col=0)
+    assert list(back.columns) == list(res.columns) and len(back) == 8
+    target = ad.get_frame_dets('groundtruth', None, libmot=True)
+    D = orc.all_path_matrices(dets, 1024, 1024)
+    n_perfect = 0
+    for _, row in res.iterrows():
+        Po = dict(orc.DEFAULTS, MCF_EDGE_COST_THR=row.edge_cost_thr, MCF_ENTRY_EXIT_COST=row.entry_exit_cost,
+                  MCF_MISS_RATE=row.miss_rate, MCF_VIS_SIM_WEIGHT=row.vis_sim_weight, MCF_CONF_CAPPING_METHOD=row.conf_capping_method)
+        trajs, _ = orc.mcf_solve(dets, D, Po)
+        rows = [[f, i, dets[f][1][k] - 35, dets[f][2][k] - 35] for i, tr in enumerate(trajs or []) for f, k in tr]
+        pred = pd.DataFrame(rows, columns=['FrameId', 'Id', 'X', 'Y']).set_index(['FrameId', 'Id']) if rows else None
+        want = mot_metrics.summarize(mot_metrics.compare_to_groundtruth(target, pred, 23.0 ** 2))
+        got = row[mot_metrics.MOTCHALLENGE_METRICS].astype(float)
+        assert np.allclose(got.to_numpy(), want.to_numpy(), rtol=0, atol=1e-12, equal_nan=True), (row, want)
+        perfect = row.mota == 1 and row.idf1 == 1 and row.num_switches == 0
+        is_label_combo = (row.edge_cost_thr == P['MCF_EDGE_COST_THR'] and row.entry_exit_cost == P['MCF_ENTRY_EXIT_COST']
+                          and row.conf_capping_method == P['MCF_CONF_CAPPING_METHOD'])
+        assert perfect or not is_label_combo
+        n_perfect += perfect
+    assert 1 <= n_perfect < 8                       # the grid does change the association
