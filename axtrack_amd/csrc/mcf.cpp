@@ -14,9 +14,11 @@
 //   * solve_lsap (fast path). Without the bound on F the problem is a sparse rectangular assignment: row k = the
 //     "out slot" of detection k, matched to the in-slot R_b of a successor b (cost obs_k + trans_kb: b's entry
 //     cost is refunded), to its own in-slot R_k (cost 0: k unused) or to a private exit column X_k
-//     (cost obs_k + entry_k + exit_k). Rows are inserted in frame order by shortest augmenting paths on reduced
+//     (cost obs_k + entry_k + exit_k). Rows are inserted in a shuffled order by shortest augmenting paths on reduced
 //     costs (Jonker-Volgenant / Crouse); a search ends at the first free column and X_k is always free, so
 //     searches stay local instead of sweeping the whole network. Its optimum is the flow optimum over all F.
+//     Blocks of frames are solved concurrently on host threads and joined through the few rows between them
+//     (Lsap::run); the optimum is unique, so the thread count does not change the result.
 //   * solve_ssp (general path): successive shortest s-t paths with Johnson potentials (first potentials from one
 //     DP sweep over the frame-ordered DAG). Used when the unconstrained optimum has F outside [min_flow, max_flow].
 // Arc costs carry a 16-bit identity hash (axt_arc_cost_int) that makes the optimum unique, so both solvers (and
@@ -28,7 +30,9 @@
 #include <time.h>
 
 #include <algorithm>
+#include <mutex>
 #include <queue>
+#include <thread>
 #include <vector>
 
 #include "../../include/axtrack_hip.h"
@@ -194,12 +198,24 @@ struct Lsap {
     std::vector<Col> c;
     std::vector<Row> rw;
     std::vector<Arc> arcs;
-    std::vector<int32_t> sr_rows, sc_cols;
-    std::vector<std::pair<int64_t, int32_t>> heap;   // binary min-heap of (key, column), storage reused
-    uint32_t search = 0;
     size_t stat_rows = 0, stat_relax = 0, stat_push = 0;
+    std::mutex stat_lock;
 
     typedef std::pair<int64_t, int32_t> Item;
+    // One thread's search state. Several of them work on the shared rows / columns at the same time, on index ranges
+    // that cannot meet (see run()).
+    struct Search {
+    Lsap &L;
+    std::vector<int32_t> sr_rows, sc_cols;
+    std::vector<Item> heap;                           // min-heap of (key, column), storage reused
+    uint32_t search;                                  // stamps above every stamp already left in this task's columns
+    size_t stat_rows = 0, stat_relax = 0, stat_push = 0;
+    Search(Lsap &l, uint32_t first) : L(l), search(first) {}
+    ~Search()
+    {
+        std::lock_guard<std::mutex> g(L.stat_lock);
+        L.stat_rows += stat_rows; L.stat_relax += stat_relax; L.stat_push += stat_push;
+    }
     // 4-ary min-heap with lazy deletion (stale entries are skipped when popped)
     void heap_push(Item it)
     {
@@ -238,6 +254,10 @@ struct Lsap {
 
     void insert_row(int i)
     {
+        std::vector<Col> &c = L.c;
+        std::vector<Row> &rw = L.rw;
+        const std::vector<Arc> &arcs = L.arcs;
+        const int n = L.n;
         heap.clear();
         search += 2;
         const uint32_t open = search, closed = search + 1;
@@ -310,33 +330,140 @@ struct Lsap {
         stat_rows += sr_rows.size();
     }
 
-    void run()
+    // rows in a fixed pseudo-random order (xorshift64 seeded by the first row: the same at any thread count)
+    void insert_shuffled(int lo, int hi)
     {
-        const double t0 = now_ms();
-        c.assign(2 * (size_t)n, Col{0, 0, -1, -1, -1, 0});
-        rw.resize(n);
-        arcs.resize((size_t)row_ptr[n]);
-        for (int k = 0; k < n; ++k) {
-            const int64_t lo = row_ptr[k], hi = row_ptr[k + 1];
-            rw[k] = Row{0, obs[k] + entry[k], obs[k] + entry[k] + exitc[k], lo, (int32_t)(hi - lo), -1, -1, 0};
-            for (int64_t e = lo; e < hi; ++e) {                             // insertion sort: rows are short
-                const int64_t w = cost[e] - entry[col[e]];
-                int64_t q = e;
-                while (q > lo && arcs[q - 1].w > w) { arcs[q] = arcs[q - 1]; --q; }
-                arcs[q] = Arc{w, col[e], (int32_t)e};
-            }
-        }
-        std::vector<int32_t> order(n);
-        for (int i = 0; i < n; ++i) order[i] = i;
-        uint64_t x = 88172645463325252ull;                                  // xorshift64: a fixed permutation
-        for (int i = n - 1; i > 0; --i) {
+        const int m = hi - lo;
+        if (m <= 0) return;
+        std::vector<int32_t> order(m);
+        for (int i = 0; i < m; ++i) order[i] = lo + i;
+        uint64_t x = 88172645463325252ull ^ ((uint64_t)lo * 0x9e3779b97f4a7c15ull);
+        if (!x) x = 88172645463325252ull;
+        for (int i = m - 1; i > 0; --i) {
             x ^= x << 13; x ^= x >> 7; x ^= x << 17;
             std::swap(order[i], order[x % (uint64_t)(i + 1)]);
         }
+        for (int i = 0; i < m; ++i) insert_row(order[i]);
+    }
+    };  // struct Search
+
+    // ---- time blocks ---------------------------------------------------------------------------------------
+    // Row k only reaches columns R_k, X_k and R_b of its successors b > k, all within reach[k] = max b. Cut the rows at
+    // p: with q = 1 + max reach of the rows before p, the rows [0,p) use columns below q and the rows [q,n) columns
+    // from q on -- two independent assignment problems as long as the rows [p,q) (two frames of detections for the
+    // tracker's networks) stay out. So: leaves of a binary tree = blocks of rows solved concurrently, inner nodes =
+    // the separator rows between two finished halves, inserted by ordinary augmenting-path searches (which cannot
+    // leave the two halves: the next separator's rows are not in yet). Row insertion reaches the one optimum in any
+    // order, so the result does not depend on the number of threads.
+    std::vector<int32_t> cut_p, cut_q;        // leaf i = rows [cut_q[i], cut_p[i+1]), separator i = rows [cut_p[i], cut_q[i])
+
+    uint32_t solve_tree(int a, int b)
+    {
+        if (b - a == 1) {
+            const double t0 = now_ms();
+            Search w(*this, 0);
+            w.insert_shuffled(cut_q[a], cut_p[a + 1]);
+            if (getenv("AXT_MCF_DEBUG")) fprintf(stderr, "  leaf %d: rows [%d,%d) scanned %zu, %.1f ms\n", a, cut_q[a], cut_p[a + 1], w.stat_rows, now_ms() - t0);
+            return w.search + 2;
+        }
+        const int m = (a + b) / 2;
+        uint32_t left = 0, right = 0;
+        bool spawned = false;
+        std::thread t;
+        try {
+            t = std::thread([&] { left = solve_tree(a, m); });
+            spawned = true;
+        } catch (...) {
+        }
+        if (!spawned) left = solve_tree(a, m);
+        right = solve_tree(m, b);
+        if (spawned) t.join();
+        const double t0 = now_ms();
+        Search w(*this, left > right ? left : right);
+        w.insert_shuffled(cut_p[m], cut_q[m]);
+        if (getenv("AXT_MCF_DEBUG")) fprintf(stderr, "  separator %d (of leaves %d..%d): rows [%d,%d) scanned %zu, %.1f ms\n", m, a, b, cut_p[m], cut_q[m], w.stat_rows, now_ms() - t0);
+        return w.search + 2;
+    }
+
+    static int thread_budget()
+    {
+        if (const char *e = getenv("AXT_MCF_THREADS")) {
+            const int v = atoi(e);
+            if (v >= 1) return v < 256 ? v : 256;
+        }
+        const unsigned hc = std::thread::hardware_concurrency();
+        return hc == 0 ? 1 : (hc > 16 ? 16 : (int)hc);        // a GPU's share of the host's cores
+    }
+
+    void run()
+    {
+        const double t0 = now_ms();
+        const int budget = thread_budget();
+        c.assign(2 * (size_t)n, Col{0, 0, -1, -1, -1, 0});
+        rw.resize(n);
+        arcs.resize((size_t)row_ptr[n]);
+        std::vector<int32_t> reach(n);
+        auto setup = [&](int k0, int k1) {
+            for (int k = k0; k < k1; ++k) {
+                const int64_t lo = row_ptr[k], hi = row_ptr[k + 1];
+                rw[k] = Row{0, obs[k] + entry[k], obs[k] + entry[k] + exitc[k], lo, (int32_t)(hi - lo), -1, -1, 0};
+                int32_t far = k;
+                for (int64_t e = lo; e < hi; ++e) {                             // insertion sort: rows are short
+                    const int64_t w = cost[e] - entry[col[e]];
+                    int64_t q = e;
+                    while (q > lo && arcs[q - 1].w > w) { arcs[q] = arcs[q - 1]; --q; }
+                    arcs[q] = Arc{w, col[e], (int32_t)e};
+                    if (col[e] > far) far = col[e];
+                }
+                reach[k] = far;
+            }
+        };
+        {
+            const int parts = n >= 4096 ? budget : 1;
+            std::vector<std::thread> pool;
+            for (int t = 1; t < parts; ++t) {
+                const int k0 = (int)((int64_t)n * t / parts), k1 = (int)((int64_t)n * (t + 1) / parts);
+                try { pool.emplace_back(setup, k0, k1); } catch (...) { setup(k0, k1); }
+            }
+            setup(0, (int)((int64_t)n / parts));
+            for (std::thread &t : pool) t.join();
+        }
+        // leaves: a power of two, at least kMinLeaf rows each, separators that do not run into the next cut
+        int kMinLeaf = 1024;
+        if (const char *e = getenv("AXT_MCF_MIN_LEAF")) kMinLeaf = atoi(e) >= 1 ? atoi(e) : 1;    // tests: force the tree on small networks
+        int leaves = 1;
+        while (leaves * 2 <= budget && n / (leaves * 2) >= kMinLeaf) leaves *= 2;
+        for (; leaves > 1; leaves /= 2) {
+            cut_p.assign(leaves + 1, 0);
+            cut_q.assign(leaves + 1, 0);
+            cut_p[leaves] = cut_q[leaves] = n;
+            std::vector<int32_t> want(leaves);
+            for (int i = 1; i < leaves; ++i) want[i] = (int32_t)((int64_t)n * i / leaves);
+            bool ok = true;
+            int32_t far = -1;
+            int next = 1;
+            for (int k = 0; k < n && next < leaves; ++k) {
+                while (next < leaves && k == want[next]) {
+                    cut_p[next] = k;
+                    cut_q[next] = far + 1 > k ? far + 1 : k;
+                    ++next;
+                }
+                if (reach[k] > far) far = reach[k];
+            }
+            for (int i = 1; i < leaves && ok; ++i)
+                ok = cut_q[i] <= cut_p[i + 1] && cut_q[i] - cut_p[i] < (cut_p[i + 1] - cut_p[i]) / 2;
+            if (ok) break;
+        }
+        if (leaves <= 1) {
+            leaves = 1;
+            cut_p.assign(2, 0); cut_q.assign(2, 0);
+            cut_p[1] = cut_q[1] = n;
+        }
         const double t1 = now_ms();
-        for (int i = 0; i < n; ++i) insert_row(order[i]);
+        solve_tree(0, leaves);
         if (getenv("AXT_MCF_DEBUG"))
-            fprintf(stderr, "lsap: n=%d rows scanned=%zu relax=%zu push=%zu  setup %.1f ms, insertions %.1f ms\n", n, stat_rows, stat_relax, stat_push, t1 - t0, now_ms() - t1);
+            fprintf(stderr, "lsap: n=%d threads<=%d leaves=%d rows scanned=%zu relax=%zu push=%zu  setup %.1f ms, insertions %.1f ms\n", n,
+                    budget, leaves, stat_rows, stat_relax, stat_push, t1 - t0, now_ms() - t1);
     }
 };
 

@@ -116,6 +116,31 @@ def test_mcf_solver_random_tracking_graphs(seed):
     assert nx.min_cost_flow_cost(G) == total
 
 
+@pytest.mark.parametrize('seed', range(12))
+def test_mcf_solver_time_blocks_on_random_timelapses(seed, monkeypatch):
+    """The time-blocked assignment solver on networks small enough for the oracle, with leaves forced down to a
+    handful of detections so that blocks, separators (also empty ones, and ones the reach test rejects) and their
+    joins all occur: trajectories and cost equal the oracle's at every thread count."""
+    rng = np.random.default_rng(100 + seed)
+    F = int(rng.integers(8, 30))
+    dets = []
+    for t in range(F):
+        n = int(rng.integers(0, 7)) if seed % 3 else int(rng.integers(3, 10))
+        conf = np.sort(rng.uniform(0.55, 1.3, n).astype(np.float32))[::-1]
+        dets.append((conf, rng.integers(0, 300, n), rng.integers(0, 300, n)))
+    if sum(len(d[0]) for d in dets) == 0:
+        return
+    P = dict(orc.DEFAULTS, MCF_MIN_FLOW=0, MCF_MAX_FLOW=1000)
+    D = orc.all_path_matrices(dets, 300, 300)
+    trajs, total = orc.mcf_solve(dets, D, P)
+    monkeypatch.setenv('AXT_MCF_MIN_LEAF', str(int(rng.integers(1, 12))))
+    for threads in ('1', '2', '4', '16'):
+        monkeypatch.setenv('AXT_MCF_THREADS', threads)
+        res, offs = _solve(dets, 300, 300, P)
+        nxt, track, n_tracks, tot = res
+        assert tot == total and tracks_from_next(nxt, track, offs) == trajs
+
+
 def test_mcf_infeasible_and_argument_errors():
     dets = [(np.array([0.9], np.float32), np.array([10]), np.array([10]))]
     P = dict(orc.DEFAULTS, MCF_MIN_FLOW=5)
@@ -135,7 +160,8 @@ def test_mcf_infeasible_and_argument_errors():
 def test_flow_solver_fast_and_general_paths_agree_at_full_size(monkeypatch):
     """The detections of the C3 bench timelapse (252 frames, 19 340 detections, captured from the GPU path into
     tests/data/c3_dets.npz): the assignment-form solver and the successive-shortest-path solver must return the same
-    optimum and the same trajectories on the full 553 k-arc network."""
+    optimum and the same trajectories on the full 553 k-arc network, and so must the assignment solver at any number
+    of threads."""
     from axtrack_amd.detections import transition_cost_table, _arc_cost_int_vec
     d = np.load(os.path.join(ROOT, 'tests', 'data', 'c3_dets.npz'))
     cnt = d['count']
@@ -169,7 +195,13 @@ def test_flow_solver_fast_and_general_paths_agree_at_full_size(monkeypatch):
     k = np.arange(n)
     obs_i, en_i, ex_i = (_arc_cost_int_vec(obs, 2, k, 0), _arc_cost_int_vec(np.full(n, 2.0), 0, k, 0),
                          _arc_cost_int_vec(np.full(n, 2.0), 1, k, 0))
+    monkeypatch.setenv('AXT_MCF_THREADS', '1')
     fast = hp.mcf_solve(obs_i, en_i, ex_i, row_ptr, b, cost, 5, 450)
+    # blocks of frames solved on concurrent threads and joined through the rows between them: the same optimum
+    for threads in ('2', '8', '16'):
+        monkeypatch.setenv('AXT_MCF_THREADS', threads)
+        par = hp.mcf_solve(obs_i, en_i, ex_i, row_ptr, b, cost, 5, 450)
+        assert par[2] == fast[2] and par[3] == fast[3] and np.array_equal(par[0], fast[0]) and np.array_equal(par[1], fast[1])
     monkeypatch.setenv('AXT_MCF_FORCE_SSP', '1')
     slow = hp.mcf_solve(obs_i, en_i, ex_i, row_ptr, b, cost, 5, 450)
     assert fast[2] == slow[2] == 63 and fast[3] == slow[3]
