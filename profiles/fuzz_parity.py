@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off randomized differential run of the whole path against the oracle (more shapes / seeds / modes than the
-committed tests): python profiles/fuzz_parity.py [n_cases]. Everything after the CNN must be identical when the oracle
+committed tests): python profiles/fuzz_parity.py [n_cases] [rng_seed]. Everything after the CNN must be identical when the oracle
 is fed the HIP YOLO grids; the CNN itself is compared with the stated tolerance."""
 import os, sys, time
 import numpy as np, torch
@@ -12,7 +12,7 @@ from oracle import oracle as orc
 from helpers import tracks_from_next
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-rng = np.random.default_rng(2024)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
 sd = synth.synth_state_dict(42)
 model = axtrack_amd.Detector(sd, max_batch=40)
 bad = 0
