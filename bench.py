@@ -193,7 +193,7 @@ def main():
             cnn_flops = sum(k['flops_per_tile'] * k['tiles'] for k in table if 'reduce' not in k['name'])
             out['roofline'] = {
                 'bound': 'mfma', 'kernel': dom['name'], 'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
-                'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': committed_traffic(dom['name']),
+                'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), **committed_traffic(dom['name']),
                 'avg_launch_ms': round(dom['ms'] / max(dom['launches'], 1), 4),
                 'flops_per_launch': flops / max(dom['launches'], 1),
                 'measured': 'HIP events around every launch of this kernel inside the timed region',
@@ -214,8 +214,9 @@ def main():
 
 
 def committed_traffic(kernel_name):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/*_traffic.json, written by profiles/summarize.py); None if no such profile matches the kernel."""
+    """roofline.traffic: HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
+    same command (profiles/*_traffic.json, written by profiles/summarize.py; the newest that matches the kernel), or
+    None if there is none."""
     import glob
     import re
     best = None
@@ -224,8 +225,11 @@ def committed_traffic(kernel_name):
         m = re.search(r'<(\d+)->(\d+)', t.get('kernel', ''))
         if m and f'{m.group(1)}>{m.group(2)}' in kernel_name.replace(' ', ''):
             best = t
-    return None if best is None else {'hbm_bytes_per_launch': best['hbm_bytes_per_launch'], 'source': 'profiles/ (rocprofv3 --pmc)',
-                                      'fetch_kb_raw': best['fetch_kb_raw'], 'write_kb': best['write_kb']}
+    if best is None:
+        return {'traffic': None}
+    return {'traffic': best['hbm_bytes_per_launch'],
+            'traffic_detail': {'unit': 'HBM bytes per launch', 'source': 'profiles/ (rocprofv3 --pmc, separate passes)',
+                               'fetch_kb_raw': best['fetch_kb_raw'], 'write_kb': best['write_kb']}}
 
 
 def cpu_baseline(args, sd, synth):
