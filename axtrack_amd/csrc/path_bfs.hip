@@ -14,8 +14,10 @@
 // Search: frontier label-correcting (parallel Bellman-Ford over worklists). Every cell of the current frontier
 // relaxes its neighbours with atomicMin on the 64-bit key; improved cells enter the next frontier once
 // (stamp array). Keys only decrease and the iteration ends when no key changes, so the fixed point is the exact
-// shortest-path key of every cell, independent of scheduling. First correct version: the frontiers live in HBM
-// and each step costs two workgroup barriers (a bit-parallel LDS variant is the planned optimisation).
+// shortest-path key of every cell, independent of scheduling. The frontiers live in HBM and each step costs two
+// workgroup barriers: this is the exact, general search (any target, paths across off-mask cells, the paths
+// themselves); the arc builder's hot path is the bit-parallel LDS search further down and falls back to this one
+// only for the rare targets that one cannot decide.
 #include "axt_common.h"
 
 #include <new>
