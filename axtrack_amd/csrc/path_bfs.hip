@@ -21,6 +21,8 @@
 #include "axt_common.h"
 
 #include <new>
+#include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 
 struct axt_grid;
@@ -207,6 +209,11 @@ struct axt_grid {
     unsigned char *d_mask = nullptr;     // [H][W] 0/1
     unsigned int *d_bits = nullptr;      // [H][Ww] bit x%32 of word x/32, zero-padded
     int *d_label = nullptr;              // [H][W] connected-component label >= 1 on the mask, 0 off it
+    // [n_comp][H][W] u8: fewest off-mask cells any path from component `label` has to enter to reach the cell (the
+    // cell itself included when it is off the mask), saturated at 255; NULL when the mask has too many components
+    unsigned char *d_off = nullptr;
+    int n_comp = 0;
+    bool has_fields = false;             // d_off covers every component (trivially so for an empty mask)
 };
 
 namespace {
@@ -361,6 +368,103 @@ __global__ __launch_bounds__(BFS_THREADS) void mask_bfs_kernel(
     }
 }
 
+// ---- targets in another component of the mask -----------------------------------------------------------------------
+// The minimum-cost path to such a target has to cross off-mask cells; its cost order is (off-mask cells entered,
+// moves). The fewest off-mask cells k* any path needs is a property of the mask (axt_grid::d_off, one 0-1 search per
+// component when the grid is created), so the per-source work shrinks to the (2R+1)^2 window that paths of <= dmax cells
+// cannot leave: a label-correcting search on keys off << 16 | moves that does not expand cells at the move limit.
+//   * optimum within the limit: every prefix of it is an optimal path of no more moves, inside the window -> the
+//     search finds exactly its key, and its off-count equals k*;
+//   * optimum longer than the limit: whatever the window search finds has a worse key but fewer moves, hence more
+//     off-mask cells than k* -> recognised, no arc.
+// k*: every path that touches the mask at all passes through some component A, so the fewest off-mask cells of such
+// paths is kA = min over A of (d_off[A][S] - [S off the mask]) + d_off[A][T] (the first term by reversing the path
+// A -> S); a source on the mask gives kA = k* = d_off[label(S)][T]. Paths that never touch the mask have as many moves
+// as off-mask cells, so if one of them is the optimum it is short enough to be found by the window search itself.
+// Hence: the window result (off, moves) is the global optimum iff off <= kA.
+constexpr int CROSS_W = 2 * BFS_R + 1;
+constexpr long CROSS_CELLS = (long)CROSS_W * CROSS_W;
+
+__global__ __launch_bounds__(256) void mask_cross_kernel(
+    const int *__restrict__ tasks, int n_tasks, const int *__restrict__ x, const int *__restrict__ y,
+    const int *__restrict__ count, int n_frames, int cap, const unsigned char *__restrict__ mask,
+    const int *__restrict__ label, const unsigned char *__restrict__ off_field, int n_comp, int H, int W, int conn8, int max_gap,
+    const int *__restrict__ dmax, unsigned int *__restrict__ key_all, int *__restrict__ stamp_all,
+    int *__restrict__ list_all, short *__restrict__ Dtmp)
+{
+    const int tid = threadIdx.x;
+    unsigned int *key = key_all + (long)blockIdx.x * CROSS_CELLS;
+    int *stamp = stamp_all + (long)blockIdx.x * CROSS_CELLS;
+    int *cur = list_all + (long)blockIdx.x * 2 * CROSS_CELLS, *nxt = cur + CROSS_CELLS;
+    __shared__ int n_cur, n_nxt;
+    __shared__ int off_s[64];                              // d_off[A][S] - [S off the mask] of the current source
+    const int nn = conn8 ? 8 : 4;
+    const int dy8[8] = {-1, 1, 0, 0, -1, -1, 1, 1}, dx8[8] = {0, 0, -1, 1, -1, 1, -1, 1};
+    int depth = 0;
+    for (int g = 0; g < max_gap; ++g) depth = max(depth, dmax[g] - 1);
+    depth = min(depth, BFS_R);
+    for (int task = blockIdx.x; task < n_tasks; task += gridDim.x) {
+        const int src = tasks[task], t = src / cap;
+        const int sx = x[src], sy = y[src];
+        const int wy0 = sy - BFS_R, wx0 = sx - BFS_R;
+        short *drow = Dtmp + (long)src * max_gap * cap;
+        __syncthreads();                                   // the previous task's readers are done with key[]
+        for (long c = tid; c < CROSS_CELLS; c += 256) { key[c] = 0xffffffffu; stamp[c] = -1; }
+        __syncthreads();
+        if (tid == 0) {
+            const int s = BFS_R * CROSS_W + BFS_R;
+            key[s] = 0;
+            cur[0] = s;
+            n_cur = 1;
+            n_nxt = 0;
+        }
+        __threadfence_block();
+        __syncthreads();
+        int *fa = cur, *fb = nxt;
+        // keys only decrease, so the frontier empties; the cap is a belt-and-braces exit every wave reaches
+        for (int iter = 0; iter < 4 * CROSS_W * CROSS_W; ++iter) {
+            const int n = n_cur;
+            if (n == 0) break;
+            for (int e = tid; e < n; e += 256) {
+                const int c = fa[e];
+                const unsigned int k = __hip_atomic_load(&key[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if ((int)(k & 0xffffu) >= depth) continue;                       // at the move limit: not expanded
+                const int cy = c / CROSS_W, cx = c - cy * CROSS_W;
+                for (int d = 0; d < nn; ++d) {
+                    const int ny = cy + dy8[d], nx = cx + dx8[d];
+                    if (ny < 0 || ny >= CROSS_W || nx < 0 || nx >= CROSS_W) continue;
+                    const int gy = wy0 + ny, gx = wx0 + nx;
+                    if (gy < 0 || gy >= H || gx < 0 || gx >= W) continue;
+                    const unsigned int nk = k + 1u + (mask[(long)gy * W + gx] == 1 ? 0u : 0x10000u);
+                    const int nc = ny * CROSS_W + nx;
+                    const unsigned int old = atomicMin(&key[nc], nk);
+                    if (nk < old && atomicExch(&stamp[nc], iter) != iter) fb[atomicAdd(&n_nxt, 1)] = nc;
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+            if (tid == 0) { n_cur = n_nxt; n_nxt = 0; }
+            int *sw = fa; fa = fb; fb = sw;
+            __syncthreads();
+        }
+        __syncthreads();
+        if (tid < n_comp)
+            off_s[tid] = (int)off_field[((long)tid * H + sy) * W + sx] - (mask[(long)sy * W + sx] == 1 ? 0 : 1);
+        __syncthreads();
+        for (int e = tid; e < max_gap * cap; e += 256) {
+            if (drow[e] != -1) continue;
+            const int g = e / cap, j = e - g * cap, tb = t + g + 1;
+            const int tx = x[(long)tb * cap + j], ty = y[(long)tb * cap + j];
+            int ka = 0x7fffffff;
+            for (int a = 0; a < n_comp; ++a) ka = min(ka, off_s[a] + (int)off_field[((long)a * H + ty) * W + tx]);
+            const unsigned int k = key[(long)(ty - wy0) * CROSS_W + (tx - wx0)];
+            short res = 0;
+            if (k != 0xffffffffu && (int)(k >> 16) <= ka && (int)(k & 0xffffu) + 1 <= dmax[g]) res = (short)((k & 0xffffu) + 1);
+            drow[e] = res;
+        }
+    }
+}
+
 // per source: does any target need the exact search?
 __global__ void mask_flag_kernel(const short *__restrict__ Dtmp, const int *__restrict__ count, int n_frames, int cap,
                                  int max_gap, int *__restrict__ flags, int *__restrict__ n_flagged)
@@ -421,7 +525,57 @@ extern "C" int axt_grid_create(const uint8_t *h_mask, int H, int W, int conn8, a
             }
         }
     }
+    // fewest off-mask cells from every component to every cell (0-1 breadth-first search per component)
+    g->n_comp = next;
+    std::vector<unsigned char> off;
+    constexpr int kMaxComp = 64;
+    if (next >= 1 && next <= kMaxComp && (size_t)next * H * W <= ((size_t)256 << 20)) {
+        off.assign((size_t)next * H * W, 255);
+        std::vector<int> dist((size_t)H * W);
+        std::vector<int> level, later, work;
+        for (int L = 1; L <= next; ++L) {
+            std::fill(dist.begin(), dist.end(), INT32_MAX);
+            level.clear();
+            for (long k = 0; k < (long)H * W; ++k)
+                if (label[k] == L) { dist[k] = 0; level.push_back((int)k); }
+            // Dial's buckets for weights {0, 1}: close the current level over the zero-weight (on-mask) moves, collect
+            // the off-mask cells one level up; 255 levels are all a path of <= 251 cells can use
+            for (int d = 0; d < 255 && !level.empty(); ++d) {
+                work.swap(level);
+                later.clear();
+                while (!work.empty()) {
+                    const int c = work.back();
+                    work.pop_back();
+                    if (dist[c] != d) continue;
+                    const int cy = c / W, cx = c % W;
+                    for (int q = 0; q < nn; ++q) {
+                        const int ny = cy + dy8[q], nx = cx + dx8[q];
+                        if (ny < 0 || ny >= H || nx < 0 || nx >= W) continue;
+                        const int n = ny * W + nx;
+                        const int nd = d + (m01[n] ? 0 : 1);
+                        if (nd < dist[n]) {
+                            dist[n] = nd;
+                            if (nd == d) work.push_back(n); else later.push_back(n);
+                        }
+                    }
+                }
+                level.clear();
+                for (int n : later)
+                    if (dist[n] == d + 1) level.push_back(n);
+            }
+            unsigned char *o = off.data() + (size_t)(L - 1) * H * W;
+            for (long k = 0; k < (long)H * W; ++k)
+                if (dist[k] < 255) o[k] = (unsigned char)dist[k];
+        }
+    }
+    g->has_fields = next == 0 || !off.empty();
     int rc = AXT_OK;
+    if (!off.empty() && (hipMalloc((void **)&g->d_off, off.size()) != hipSuccess ||
+                         hipMemcpy(g->d_off, off.data(), off.size(), hipMemcpyHostToDevice) != hipSuccess)) {
+        axt_set_error("axt_grid_create: device allocation for the component distance fields failed");
+        axt_grid_destroy(g);
+        return AXT_ENOMEM;
+    }
     if (hipMalloc((void **)&g->d_mask, (size_t)H * W) != hipSuccess || hipMalloc((void **)&g->d_bits, bits.size() * 4) != hipSuccess ||
         hipMalloc((void **)&g->d_label, label.size() * 4) != hipSuccess) {
         axt_set_error("axt_grid_create: device allocation failed");
@@ -443,6 +597,7 @@ extern "C" void axt_grid_destroy(axt_grid *g)
     (void)hipFree(g->d_mask);
     (void)hipFree(g->d_bits);
     (void)hipFree(g->d_label);
+    (void)hipFree(g->d_off);
     delete g;
 }
 
@@ -476,6 +631,43 @@ int axt_masked_distance_table(const axt_grid *g, const int32_t *d_x, const int32
     AXT_CHECK_HIP(hipMemcpyAsync(&nf, n_flagged, sizeof(int), hipMemcpyDeviceToHost, st));
     AXT_CHECK_HIP(hipStreamSynchronize(st));
     if (nf > 0) {
+        std::vector<int> hf((size_t)n_frames * cap), hc(n_frames);
+        AXT_CHECK_HIP(hipMemcpy(hf.data(), flags, hf.size() * 4, hipMemcpyDeviceToHost));
+        AXT_CHECK_HIP(hipMemcpy(hc.data(), d_count, (size_t)n_frames * 4, hipMemcpyDeviceToHost));
+        if (g->has_fields) {
+            // targets in other components / off the mask: windowed search of every flagged source (resolves them all)
+            std::vector<int> tasks;
+            for (int t = 0; t < n_frames; ++t)
+                for (int i = 0; i < hc[t] && i < cap; ++i)
+                    if (hf[(size_t)t * cap + i]) tasks.push_back(t * cap + i);
+            const int n_tasks = (int)tasks.size();
+            if (getenv("AXT_PATH_DEBUG")) fprintf(stderr, "masked arcs: %d sources with targets in other components (windowed search)\n", n_tasks);
+            const int wgs = n_tasks < 512 ? n_tasks : 512;
+            int *d_tasks = nullptr;
+            unsigned char *scratch = nullptr;
+            AXT_CHECK_HIP(hipMallocAsync((void **)&d_tasks, sizeof(int) * n_tasks, st));
+            AXT_CHECK_HIP(hipMallocAsync((void **)&scratch, (size_t)wgs * CROSS_CELLS * 16, st));
+            AXT_CHECK_HIP(hipMemcpyAsync(d_tasks, tasks.data(), sizeof(int) * n_tasks, hipMemcpyHostToDevice, st));
+            unsigned int *key = reinterpret_cast<unsigned int *>(scratch);
+            int *stamp = reinterpret_cast<int *>(scratch + (size_t)wgs * CROSS_CELLS * 4);
+            int *lists = reinterpret_cast<int *>(scratch + (size_t)wgs * CROSS_CELLS * 8);
+            hipLaunchKernelGGL(mask_cross_kernel, dim3(wgs), dim3(256), 0, st, (const int *)d_tasks, n_tasks, d_x, d_y, d_count,
+                               n_frames, cap, g->d_mask, (const int *)g->d_label, (const unsigned char *)g->d_off, g->n_comp, g->H, g->W,
+                               g->conn8, max_gap, d_dmax, key, stamp, lists, d_Dtmp);
+            AXT_LAUNCH_CHECK();
+            AXT_CHECK_HIP(hipMemsetAsync(n_flagged, 0, sizeof(int), st));
+            hipLaunchKernelGGL(mask_flag_kernel, dim3(cap, n_frames), dim3(64), 0, st, d_Dtmp, d_count, n_frames, cap, max_gap, flags,
+                               n_flagged);
+            AXT_LAUNCH_CHECK();
+            AXT_CHECK_HIP(hipMemcpyAsync(&nf, n_flagged, sizeof(int), hipMemcpyDeviceToHost, st));
+            AXT_CHECK_HIP(hipStreamSynchronize(st));                 // also: tasks[] may go out of scope
+            AXT_CHECK_HIP(hipFreeAsync(d_tasks, st));
+            AXT_CHECK_HIP(hipFreeAsync(scratch, st));
+            if (nf > 0) AXT_CHECK_HIP(hipMemcpy(hf.data(), flags, hf.size() * 4, hipMemcpyDeviceToHost));
+        }
+    }
+    if (nf > 0) {
+        if (getenv("AXT_PATH_DEBUG")) fprintf(stderr, "masked arcs: %d sources left for the general search\n", nf);
         std::vector<int> hf((size_t)n_frames * cap), hc(n_frames);
         AXT_CHECK_HIP(hipMemcpy(hf.data(), flags, hf.size() * 4, hipMemcpyDeviceToHost));
         AXT_CHECK_HIP(hipMemcpy(hc.data(), d_count, (size_t)n_frames * 4, hipMemcpyDeviceToHost));

@@ -489,6 +489,44 @@ def test_inference_with_mask_end_to_end(weights):
     assert got == ref['trajs'] and ad.mcf_total_cost == ref['total_cost']
 
 
+def test_full_size_properties_c5_share(weights):
+    """One GPU's share of BASELINE config 5 (1024x1024 frames with an occlusion mask, 64 detection frames, path costs on
+    the masked grid, global flow solve): properties that hold at any size. Every link of every trajectory is an
+    admissible arc whose length the exact search reproduces, trajectories are node-disjoint, and a second run is
+    identical."""
+    import axtrack_amd
+    frames = synth.synth_frames(68, 1024, 1024, seed=3)
+    mask = synth.corridor_mask(1024, 1024, width=40, pitch=128)
+    frames = frames * mask[None].astype(np.float32)
+    P = params.load_parameters()
+    model = axtrack_amd.Detector(weights, max_batch=64)
+    tl = axtrack_amd.Timelapse(frames, name='c5', mask=mask)
+    ad = axtrack_amd.inference(tl, model, None, P, None, None, None)
+    cnt, conf, x, y = ad._host_dets()
+    assert len(cnt) == 64 and cnt.sum() > 3000
+    tracks = tracks_from_next(np.zeros(len(ad._track_flat)), ad._track_flat, ad._offs)
+    assert P['MCF_MIN_FLOW'] <= len(tracks) <= P['MCF_MAX_FLOW'] and len(tracks) == ad.n_ids
+    seen, links = set(), []
+    for tr in tracks:
+        for (f0, i0), (f1, i1) in zip(tr[:-1], tr[1:]):
+            assert f1 - f0 in (1, 2)
+            links.append((f0, i0, f1, i1))
+        for node in tr:
+            assert node not in seen
+            seen.add(node)
+    assert len(links) > 1000
+    # the exact search on a sample of links: the length that made the arc admissible
+    rng = np.random.default_rng(0)
+    grid = ad._mask_dev()
+    for k in rng.choice(len(links), 40, replace=False):
+        f0, i0, f1, i1 = links[k]
+        D = hp.path_cost(ad.d_x[f0, i0:i0 + 1], ad.d_y[f0, i0:i0 + 1], ad.d_x[f1, i1:i1 + 1], ad.d_y[f1, i1:i1 + 1],
+                         1024, 1024, grid, 500, False)
+        assert int(D.item()) <= (251 if f1 - f0 == 1 else 86)
+    ad2 = axtrack_amd.inference(tl, model, None, P, None, None, None)
+    assert np.array_equal(ad2._track_flat, ad._track_flat) and ad2.mcf_total_cost == ad.mcf_total_cost
+
+
 # ----------------------------------------------------------------------------------------- multi-GPU path
 def test_two_rank_frame_sharding(weights):
     """Two ranks (gloo, both on cuda:0) each detect half of the frames, all-gather the detections and run the
