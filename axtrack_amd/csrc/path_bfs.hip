@@ -389,14 +389,13 @@ __global__ __launch_bounds__(256) void mask_cross_kernel(
     const int *__restrict__ tasks, int n_tasks, const int *__restrict__ x, const int *__restrict__ y,
     const int *__restrict__ count, int n_frames, int cap, const unsigned char *__restrict__ mask,
     const int *__restrict__ label, const unsigned char *__restrict__ off_field, int n_comp, int H, int W, int conn8, int max_gap,
-    const int *__restrict__ dmax, unsigned int *__restrict__ key_all, int *__restrict__ stamp_all,
-    int *__restrict__ list_all, short *__restrict__ Dtmp)
+    const int *__restrict__ dmax, unsigned int *__restrict__ key_all, int *__restrict__ list_all,
+    short *__restrict__ Dtmp)
 {
     const int tid = threadIdx.x;
     unsigned int *key = key_all + (long)blockIdx.x * CROSS_CELLS;
-    int *stamp = stamp_all + (long)blockIdx.x * CROSS_CELLS;
     int *cur = list_all + (long)blockIdx.x * 2 * CROSS_CELLS, *nxt = cur + CROSS_CELLS;
-    __shared__ int n_cur, n_nxt;
+    __shared__ int n_cur, n_nxt, overflow;
     __shared__ int off_s[64];                              // d_off[A][S] - [S off the mask] of the current source
     const int nn = conn8 ? 8 : 4;
     const int dy8[8] = {-1, 1, 0, 0, -1, -1, 1, 1}, dx8[8] = {0, 0, -1, 1, -1, 1, -1, 1};
@@ -409,7 +408,7 @@ __global__ __launch_bounds__(256) void mask_cross_kernel(
         const int wy0 = sy - BFS_R, wx0 = sx - BFS_R;
         short *drow = Dtmp + (long)src * max_gap * cap;
         __syncthreads();                                   // the previous task's readers are done with key[]
-        for (long c = tid; c < CROSS_CELLS; c += 256) { key[c] = 0xffffffffu; stamp[c] = -1; }
+        for (long c = tid; c < CROSS_CELLS; c += 256) key[c] = 0xffffffffu;
         __syncthreads();
         if (tid == 0) {
             const int s = BFS_R * CROSS_W + BFS_R;
@@ -417,6 +416,7 @@ __global__ __launch_bounds__(256) void mask_cross_kernel(
             cur[0] = s;
             n_cur = 1;
             n_nxt = 0;
+            overflow = 0;
         }
         __threadfence_block();
         __syncthreads();
@@ -435,15 +435,22 @@ __global__ __launch_bounds__(256) void mask_cross_kernel(
                     if (ny < 0 || ny >= CROSS_W || nx < 0 || nx >= CROSS_W) continue;
                     const int gy = wy0 + ny, gx = wx0 + nx;
                     if (gy < 0 || gy >= H || gx < 0 || gx >= W) continue;
-                    const unsigned int nk = k + 1u + (mask[(long)gy * W + gx] == 1 ? 0u : 0x10000u);
                     const int nc = ny * CROSS_W + nx;
+                    // most relaxations fail (a cell is improved once or twice but reached from every side): look first
+                    const unsigned int seen = __hip_atomic_load(&key[nc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if ((seen >> 16) == 0u && seen <= k + 1u) continue;                  // cannot be beaten, whatever the cell is
+                    const unsigned int nk = k + 1u + (mask[(long)gy * W + gx] == 1 ? 0u : 0x10000u);
+                    if (seen <= nk) continue;
                     const unsigned int old = atomicMin(&key[nc], nk);
-                    if (nk < old && atomicExch(&stamp[nc], iter) != iter) fb[atomicAdd(&n_nxt, 1)] = nc;
+                    if (nk < old) {                  // a cell improved twice in one round is listed twice: harmless
+                        const int slot = atomicAdd(&n_nxt, 1);
+                        if (slot < (int)CROSS_CELLS) fb[slot] = nc; else overflow = 1;
+                    }
                 }
             }
             __threadfence_block();
             __syncthreads();
-            if (tid == 0) { n_cur = n_nxt; n_nxt = 0; }
+            if (tid == 0) { n_cur = min(n_nxt, (int)CROSS_CELLS); n_nxt = 0; }
             int *sw = fa; fa = fb; fb = sw;
             __syncthreads();
         }
@@ -452,7 +459,7 @@ __global__ __launch_bounds__(256) void mask_cross_kernel(
             off_s[tid] = (int)off_field[((long)tid * H + sy) * W + sx] - (mask[(long)sy * W + sx] == 1 ? 0 : 1);
         __syncthreads();
         for (int e = tid; e < max_gap * cap; e += 256) {
-            if (drow[e] != -1) continue;
+            if (drow[e] != -1 || overflow) continue;              // (a list overflowed: the general search takes the source)
             const int g = e / cap, j = e - g * cap, tb = t + g + 1;
             const int tx = x[(long)tb * cap + j], ty = y[(long)tb * cap + j];
             int ka = 0x7fffffff;
@@ -642,19 +649,27 @@ int axt_masked_distance_table(const axt_grid *g, const int32_t *d_x, const int32
                     if (hf[(size_t)t * cap + i]) tasks.push_back(t * cap + i);
             const int n_tasks = (int)tasks.size();
             if (getenv("AXT_PATH_DEBUG")) fprintf(stderr, "masked arcs: %d sources with targets in other components (windowed search)\n", n_tasks);
-            const int wgs = n_tasks < 512 ? n_tasks : 512;
+            const int wgs = n_tasks < 512 ? n_tasks : 512;       // two per CU; more only thrash the caches (measured)
             int *d_tasks = nullptr;
             unsigned char *scratch = nullptr;
             AXT_CHECK_HIP(hipMallocAsync((void **)&d_tasks, sizeof(int) * n_tasks, st));
-            AXT_CHECK_HIP(hipMallocAsync((void **)&scratch, (size_t)wgs * CROSS_CELLS * 16, st));
+            AXT_CHECK_HIP(hipMallocAsync((void **)&scratch, (size_t)wgs * CROSS_CELLS * 12, st));
             AXT_CHECK_HIP(hipMemcpyAsync(d_tasks, tasks.data(), sizeof(int) * n_tasks, hipMemcpyHostToDevice, st));
             unsigned int *key = reinterpret_cast<unsigned int *>(scratch);
-            int *stamp = reinterpret_cast<int *>(scratch + (size_t)wgs * CROSS_CELLS * 4);
-            int *lists = reinterpret_cast<int *>(scratch + (size_t)wgs * CROSS_CELLS * 8);
+            int *lists = reinterpret_cast<int *>(scratch + (size_t)wgs * CROSS_CELLS * 4);
+            const bool timed = getenv("AXT_PATH_DEBUG") != nullptr;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (timed) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st); }
             hipLaunchKernelGGL(mask_cross_kernel, dim3(wgs), dim3(256), 0, st, (const int *)d_tasks, n_tasks, d_x, d_y, d_count,
                                n_frames, cap, g->d_mask, (const int *)g->d_label, (const unsigned char *)g->d_off, g->n_comp, g->H, g->W,
-                               g->conn8, max_gap, d_dmax, key, stamp, lists, d_Dtmp);
+                               g->conn8, max_gap, d_dmax, key, lists, d_Dtmp);
             AXT_LAUNCH_CHECK();
+            if (timed) {
+                float ms = 0;
+                (void)hipEventRecord(e1, st); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1);
+                fprintf(stderr, "masked arcs: windowed search of %d sources took %.1f ms\n", n_tasks, ms);
+                (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+            }
             AXT_CHECK_HIP(hipMemsetAsync(n_flagged, 0, sizeof(int), st));
             hipLaunchKernelGGL(mask_flag_kernel, dim3(cap, n_frames), dim3(64), 0, st, d_Dtmp, d_count, n_frames, cap, max_gap, flags,
                                n_flagged);

@@ -768,15 +768,21 @@ def test_example_script_runs_the_three_step_api(tmp_path):
 
 
 @pytest.mark.parametrize('conn8', [False, True])
-def test_build_arcs_masked_grid_matches_oracle(conn8):
-    """The bit-parallel on-mask BFS + connected components + exact fallback must give exactly the arcs the oracle's
-    per-pair searches give: corridor mask with a gap and a disconnected island, detections on and off the mask."""
+@pytest.mark.parametrize('comb', [False, True])
+def test_build_arcs_masked_grid_matches_oracle(conn8, comb):
+    """The bit-parallel on-mask BFS + connected components + the windowed search for targets in other components /
+    off the mask must give exactly the arcs the oracle's per-pair searches give: corridor mask with a gap and a
+    disconnected island, detections on and off the mask. comb: a bar along the top joins the corridors into one
+    component, so neighbouring corridors are connected on the mask -- by detours that are mostly too long to count,
+    although crossing the wall would be short."""
     from axtrack_amd.detections import transition_cost_table
     H, W = 300, 420
     mask = synth.corridor_mask(H, W, width=24, pitch=80)
     mask[100:140, :] = False
     mask[110:130, 200:260] = True                               # an island: on the mask but in its own component
-    rng = np.random.default_rng(11 + conn8)
+    if comb:
+        mask[0:6, :] = True
+    rng = np.random.default_rng(11 + conn8 + 2 * comb)
     F, cap = 5, 40
     ys, xs = np.nonzero(mask)
     dets = []
