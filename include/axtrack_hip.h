@@ -177,8 +177,10 @@ int axt_path_cells(const int32_t *d_xa, const int32_t *d_ya, int na,
  * axt_arc_cost_int-compatible values (units << 16 | hash16(3, a, b)). Both NULL to skip.
  * grid = NULL: all-ones mask, closed-form path lengths. With a grid, path lengths come from one bit-parallel
  * breadth-first search per detection over the on-mask cells (depth h_dmax-1 <= 250 moves; connected components
- * decide which targets that search can reach) and, for the rare targets only reachable across off-mask cells,
- * from the exact search of axt_path_cost. */
+ * decide which targets that search can reach) and, for targets in other components or off the mask, from a
+ * label-correcting search on (off-mask cells, moves) inside the window paths of <= dmax cells cannot leave, checked
+ * against the per-component off-cell counts the grid holds (masks with more than 64 components: the exact search of
+ * axt_path_cost). */
 int axt_build_arcs(const int32_t *d_x, const int32_t *d_y, const int32_t *d_count, int n_frames, int cap,
                    const axt_grid *grid, int H, int W, int max_dist, int conn8,
                    int max_gap, const int32_t *h_dmax,
