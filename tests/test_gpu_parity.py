@@ -251,14 +251,16 @@ def test_ided_dets_all_reproduces_the_references_table(golden, weights):
     assert df.index.name == 'axonID' and list(df.columns.names) == ['frameID', 'detInfo']
 
 
-def test_full_size_properties_c3(weights):
-    """BASELINE config 3 size (512x512x256): properties that hold at any size."""
-    frames = synth.synth_frames(256, 512, 512, seed=0)
+@pytest.mark.parametrize('T_all,size,name', [(256, 512, 'c3'), (132, 1024, 'c4')])
+def test_full_size_properties(weights, T_all, size, name):
+    """BASELINE config 3 (512x512x256) and one GPU's share of config 4 (1024x1024, 128 detection frames, global flow
+    solve): properties that hold at any size."""
+    frames = synth.synth_frames(T_all, size, size, seed=0)
     P = params.load_parameters()
-    ad = _run_inference(frames, weights, P, name='c3')
+    ad = _run_inference(frames, weights, P, name=name)
     cnt, conf, x, y = ad._host_dets()
-    assert len(cnt) == 252 and cnt.min() > 0
-    for t in range(0, 252, 17):
+    assert len(cnt) == T_all - 4 and cnt.min() > 0
+    for t in range(0, T_all - 4, 17):
         n = int(cnt[t])
         assert np.all(np.diff(conf[t, :n].astype(np.float64)) <= 0)                     # sorted
         d2 = (x[t, :n, None] - x[t, None, :n]).astype(np.int64) ** 2 + (y[t, :n, None] - y[t, None, :n]).astype(np.int64) ** 2
@@ -279,7 +281,7 @@ def test_full_size_properties_c3(weights):
             assert node not in seen                                                   # node-disjoint
             seen.add(node)
     # idempotence: a second run gives identical results (bit-reproducible kernels, unique optimum)
-    ad2 = _run_inference(frames, weights, P, name='c3')
+    ad2 = _run_inference(frames, weights, P, name=name)
     assert np.array_equal(ad2._track_flat, ad._track_flat) and ad2.mcf_total_cost == ad.mcf_total_cost
     assert torch.equal(ad2._yolo, ad._yolo)
 
