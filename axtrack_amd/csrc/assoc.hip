@@ -21,8 +21,8 @@ int axt_path_cost_masked(const int32_t *d_xa, const int32_t *d_ya, int na, const
 struct axt_grid;
 extern "C" const uint8_t *axt_grid_mask(const axt_grid *g);
 int axt_masked_distance_table(const axt_grid *g, const int32_t *d_x, const int32_t *d_y, const int32_t *d_count,
-                              int n_frames, int cap, int max_dist, int max_gap, const int32_t *h_dmax,
-                              const int32_t *d_dmax, int16_t *d_Dtmp, hipStream_t st);
+                              const int32_t *d_src_count, int n_frames, int cap, int max_dist, int max_gap,
+                              const int32_t *h_dmax, const int32_t *d_dmax, int16_t *d_Dtmp, hipStream_t st);
 
 namespace {
 
@@ -145,7 +145,7 @@ __device__ __forceinline__ double vis_transition_cost(const VisParams &vp, const
 
 template <bool FILL, bool TABLE, bool VIS>
 __global__ __launch_bounds__(256) void arcs_open_kernel(
-    const int *__restrict__ x, const int *__restrict__ y, const int *__restrict__ count,
+    const int *__restrict__ x, const int *__restrict__ y, const int *__restrict__ count, const int *__restrict__ src_count,
     const int *__restrict__ frame_off, int n_frames, int cap, int H, int W, int max_dist, int conn8, int max_gap,
     const int *__restrict__ dmax, int *__restrict__ cnt, const long *__restrict__ row_ptr,
     int *__restrict__ col, short *__restrict__ len, unsigned char *__restrict__ gapv,
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void arcs_open_kernel(
 {
     __shared__ float ha_s[VIS ? 4 : 1][VIS ? 180 : 1];
     const int t = blockIdx.x;
-    const int na = min(count[t], cap);
+    const int na = min(src_count[t], cap);             // rows are built for these (a frame-sharded rank: its own frames)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int waves = blockDim.x >> 6;
     for (int w = blockIdx.y * waves + wave; w < na * max_gap; w += gridDim.y * waves) {
@@ -301,8 +301,9 @@ static int build_arcs_impl(const int32_t *d_x, const int32_t *d_y, const int32_t
                            const axt_grid *grid, int H, int W, int max_dist, int conn8, int max_gap, const int32_t *h_dmax,
                            int64_t *d_row_ptr, int32_t *d_work, int32_t *d_col, int16_t *d_len, uint8_t *d_gap,
                            const int64_t *d_cost_units, int64_t *d_cost, int64_t *n_arcs, const VisParams *vis,
-                           const int16_t *d_ext_table, void *stream)
+                           const int16_t *d_ext_table, void *stream, const int32_t *d_src_count = nullptr)
 {
+    const int32_t *src_count = d_src_count ? d_src_count : d_count;
     AXT_REQUIRE(d_x && d_y && d_count && h_dmax && d_row_ptr && d_work && n_arcs, "null argument");
     AXT_REQUIRE(n_frames >= 1 && cap >= 1 && max_gap >= 1 && max_gap <= 8, "bad argument");
     hipStream_t st = (hipStream_t)stream;
@@ -320,7 +321,7 @@ static int build_arcs_impl(const int32_t *d_x, const int32_t *d_y, const int32_t
     const VisParams vp = vis ? *vis : VisParams{};
     // the four (table, appearance) variants of one pass
     auto launch = [&](auto kern) {
-        hipLaunchKernelGGL(kern, grid_dim, block, 0, st, d_x, d_y, d_count, frame_off, n_frames, cap, H, W, max_dist, conn8,
+        hipLaunchKernelGGL(kern, grid_dim, block, 0, st, d_x, d_y, d_count, src_count, frame_off, n_frames, cap, H, W, max_dist, conn8,
                            max_gap, dmax, cnt, fill ? (const long *)d_row_ptr : (const long *)nullptr, fill ? d_col : (int *)nullptr,
                            fill ? d_len : (short *)nullptr, fill ? d_gap : (unsigned char *)nullptr,
                            fill ? (const long *)d_cost_units : (const long *)nullptr, fill ? (long *)d_cost : (long *)nullptr,
@@ -331,10 +332,12 @@ static int build_arcs_impl(const int32_t *d_x, const int32_t *d_y, const int32_t
         hipLaunchKernelGGL(frame_offsets_kernel, dim3(1), dim3(1024), 0, st, d_count, n_frames, cap, frame_off);
         AXT_LAUNCH_CHECK();
         if (grid && !d_ext_table) {
-            const int rc = axt_masked_distance_table(grid, d_x, d_y, d_count, n_frames, cap, max_dist, max_gap, h_dmax, dmax,
-                                                     const_cast<short *>(Dtmp), st);
+            const int rc = axt_masked_distance_table(grid, d_x, d_y, d_count, src_count, n_frames, cap, max_dist, max_gap, h_dmax,
+                                                     dmax, const_cast<short *>(Dtmp), st);
             if (rc) return rc;
         }
+        if (d_src_count)         // rows of other ranks' frames stay empty
+            AXT_CHECK_HIP(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)n_frames * cap * max_gap, st));
         if (table && vis) launch(arcs_open_kernel<false, true, true>);
         else if (table) launch(arcs_open_kernel<false, true, false>);
         else if (vis) launch(arcs_open_kernel<false, false, true>);
@@ -397,6 +400,29 @@ int axt_build_arcs_vis(const int32_t *d_x, const int32_t *d_y, const int32_t *d_
     for (int g = 0; g < 8; ++g) vp.mp[g] = pow(miss_rate, (double)g);          // miss_rate ** (gap - 1), as Python computes it
     return build_arcs_impl(d_x, d_y, d_count, n_frames, cap, grid, H, W, max_dist, conn8, max_gap, h_dmax, d_row_ptr, d_work,
                            d_col, d_len, d_gap, nullptr, d_cost, n_arcs, &vp, nullptr, stream);
+}
+
+int axt_build_arcs_rows(const int32_t *d_x, const int32_t *d_y, const int32_t *d_count, const int32_t *d_src_count,
+                        int n_frames, int cap, const axt_grid *grid, int H, int W, int max_dist, int conn8, int max_gap,
+                        const int32_t *h_dmax, const float *d_hist, const double *d_hist_sum, double vis_weight,
+                        double miss_rate, double edge_cost_thr, int64_t *d_row_ptr, int32_t *d_work, int32_t *d_col,
+                        int16_t *d_len, uint8_t *d_gap, const int64_t *d_cost_units, int64_t *d_cost, int64_t *n_arcs,
+                        void *stream)
+{
+    AXT_REQUIRE(d_src_count, "axt_build_arcs_rows: null source counts");
+    if (!d_hist)
+        return build_arcs_impl(d_x, d_y, d_count, n_frames, cap, grid, H, W, max_dist, conn8, max_gap, h_dmax, d_row_ptr, d_work,
+                               d_col, d_len, d_gap, d_cost_units, d_cost, n_arcs, nullptr, nullptr, stream, d_src_count);
+    AXT_REQUIRE(d_hist_sum, "axt_build_arcs_rows: null histogram sums");
+    AXT_REQUIRE(vis_weight > 0.0 && vis_weight <= 1.0, "axt_build_arcs_rows: weight %g outside (0,1]", vis_weight);
+    VisParams vp;
+    vp.hist = d_hist;
+    vp.hsum = d_hist_sum;
+    vp.w = vis_weight;
+    vp.thr = edge_cost_thr;
+    for (int g = 0; g < 8; ++g) vp.mp[g] = pow(miss_rate, (double)g);
+    return build_arcs_impl(d_x, d_y, d_count, n_frames, cap, grid, H, W, max_dist, conn8, max_gap, h_dmax, d_row_ptr, d_work,
+                           d_col, d_len, d_gap, nullptr, d_cost, n_arcs, &vp, nullptr, stream, d_src_count);
 }
 
 }  // extern "C"

@@ -233,9 +233,9 @@ __device__ __forceinline__ unsigned int dil_h(const unsigned int *row, int w)
 constexpr int BFS_THREADS = 1024;      // one workgroup per CU (LDS-bound): many waves hide the LDS latency of the sweeps
 
 __global__ __launch_bounds__(BFS_THREADS) void mask_bfs_kernel(
-    const int *__restrict__ x, const int *__restrict__ y, const int *__restrict__ count, int n_frames, int cap,
-    const unsigned int *__restrict__ bits, const int *__restrict__ label, int H, int W, int Ww, int conn8,
-    int max_dist, int max_gap, const int *__restrict__ dmax, short *__restrict__ Dtmp)
+    const int *__restrict__ x, const int *__restrict__ y, const int *__restrict__ count, const int *__restrict__ src_count,
+    int n_frames, int cap, const unsigned int *__restrict__ bits, const int *__restrict__ label, int H, int W, int Ww,
+    int conn8, int max_dist, int max_gap, const int *__restrict__ dmax, short *__restrict__ Dtmp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned int bsm[];
     unsigned int *A = bsm, *Bm = A + BFS_WH * BFS_WW, *M = Bm + BFS_WH * BFS_WW;
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(BFS_THREADS) void mask_bfs_kernel(
     __shared__ int n_slab, n_open;
 
     const int t = blockIdx.y, i = blockIdx.x, tid = threadIdx.x;
-    if (i >= min(count[t], cap)) return;
+    if (i >= min(src_count[t], cap)) return;
     const int sx = x[(long)t * cap + i], sy = y[(long)t * cap + i];
     short *drow = Dtmp + ((long)t * cap + i) * max_gap * cap;
     const bool s_in = sx >= 0 && sx < W && sy >= 0 && sy < H;
@@ -612,8 +612,8 @@ extern "C" const uint8_t *axt_grid_mask(const axt_grid *g) { return g ? g->d_mas
 
 // Fills Dtmp (layout above) for every source detection; exact-search fallback included. Synchronises the stream.
 int axt_masked_distance_table(const axt_grid *g, const int32_t *d_x, const int32_t *d_y, const int32_t *d_count,
-                              int n_frames, int cap, int max_dist, int max_gap, const int32_t *h_dmax,
-                              const int32_t *d_dmax, int16_t *d_Dtmp, hipStream_t st)
+                              const int32_t *d_src_count, int n_frames, int cap, int max_dist, int max_gap,
+                              const int32_t *h_dmax, const int32_t *d_dmax, int16_t *d_Dtmp, hipStream_t st)
 {
     for (int k = 0; k < max_gap; ++k)
         AXT_REQUIRE(h_dmax[k] - 1 <= BFS_R, "masked arcs: dmax %d exceeds the BFS window (%d cells)", h_dmax[k], BFS_R + 1);
@@ -624,14 +624,14 @@ int axt_masked_distance_table(const axt_grid *g, const int32_t *d_x, const int32
         AXT_CHECK_HIP(hipFuncSetAttribute((const void *)mask_bfs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
         attr = true;
     }
-    hipLaunchKernelGGL(mask_bfs_kernel, dim3(cap, n_frames), dim3(BFS_THREADS), lds, st, d_x, d_y, d_count, n_frames, cap, g->d_bits,
+    hipLaunchKernelGGL(mask_bfs_kernel, dim3(cap, n_frames), dim3(BFS_THREADS), lds, st, d_x, d_y, d_count, d_src_count, n_frames, cap, g->d_bits,
                        g->d_label, g->H, g->W, g->Ww, g->conn8, max_dist, max_gap, d_dmax, d_Dtmp);
     AXT_LAUNCH_CHECK();
     int *flags = nullptr, *n_flagged = nullptr;
     AXT_CHECK_HIP(hipMallocAsync((void **)&flags, sizeof(int) * ((size_t)n_frames * cap + 1), st));
     n_flagged = flags + (size_t)n_frames * cap;
     AXT_CHECK_HIP(hipMemsetAsync(n_flagged, 0, sizeof(int), st));
-    hipLaunchKernelGGL(mask_flag_kernel, dim3(cap, n_frames), dim3(64), 0, st, d_Dtmp, d_count, n_frames, cap, max_gap, flags,
+    hipLaunchKernelGGL(mask_flag_kernel, dim3(cap, n_frames), dim3(64), 0, st, d_Dtmp, d_src_count, n_frames, cap, max_gap, flags,
                        n_flagged);
     AXT_LAUNCH_CHECK();
     int nf = 0;
@@ -671,7 +671,7 @@ int axt_masked_distance_table(const axt_grid *g, const int32_t *d_x, const int32
                 (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
             }
             AXT_CHECK_HIP(hipMemsetAsync(n_flagged, 0, sizeof(int), st));
-            hipLaunchKernelGGL(mask_flag_kernel, dim3(cap, n_frames), dim3(64), 0, st, d_Dtmp, d_count, n_frames, cap, max_gap, flags,
+            hipLaunchKernelGGL(mask_flag_kernel, dim3(cap, n_frames), dim3(64), 0, st, d_Dtmp, d_src_count, n_frames, cap, max_gap, flags,
                                n_flagged);
             AXT_LAUNCH_CHECK();
             AXT_CHECK_HIP(hipMemcpyAsync(&nf, n_flagged, sizeof(int), hipMemcpyDeviceToHost, st));

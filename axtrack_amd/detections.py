@@ -526,10 +526,20 @@ class AxonDetections(object):
         len_table = getattr(self, '_len_table', None)
         if len_table is not None and vis is not None:
             raise NotImplementedError('cached path lengths together with MCF_VIS_SIM_WEIGHT > 0')
+        src_count = None
+        if shard is not None and len_table is None:
+            # frame-sharded: this rank builds the arc rows of its own frames, one all-gather joins them (the path
+            # searches of a masked grid are the expensive part of the association and shard with the frames)
+            src_count = torch.zeros_like(self.d_count)
+            src_count[shard[0]:shard[1]] = self.d_count[shard[0]:shard[1]]
         row_ptr, col, length, gap, cost = hp.build_arcs(self.d_x, self.d_y, self.d_count, self.dataset.sizey,
                                                         self.dataset.sizex, dmax, units, self._mask_dev(),
-                                                        self.max_px_assoc_dist, self.conn8, vis, len_table)
+                                                        self.max_px_assoc_dist, self.conn8, vis, len_table, src_count)
         cnt, conf, x, y = self._host_dets()
+        if src_count is not None:
+            from . import sharded
+            row_ptr, col, length, gap, cost = sharded.all_gather_arcs(row_ptr, col, length, gap, cost, int(cnt.sum()),
+                                                                      shard[2])
         offs = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
         n_det = int(offs[-1])
         obs_h = obs.cpu().numpy()

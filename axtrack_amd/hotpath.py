@@ -254,13 +254,15 @@ def box_histograms(frames, x, y, count, t_offset=2, box=AXON_BOX_SIZE):
 
 
 def build_arcs(x, y, count, H, W, dmax, cost_units=None, mask=None, max_dist=MAX_PX_ASSOC_DIST, conn8=False, vis=None,
-               length_table=None):
+               length_table=None, src_count=None):
     """Admissible transition arcs of the whole timelapse, CSR by tail detection (global numbering).
     cost_units: optional int64 [max_gap, max_dist+1] = round(transition cost * 1e6) per (gap, D).
     vis: None, or dict(hist, hsum, weight, miss_rate, thr) -- the appearance term (MCF_VIS_SIM_WEIGHT > 0): costs
     are then computed per pair on the GPU and cost_units is ignored.
     length_table: None, or i16 device tensor [F, cap, max_gap, cap] of precomputed path lengths (<= 0: none), e.g.
     from a path cache written by the reference; mask is then ignored.
+    src_count: None, or i32 [F]: build rows only for the first src_count[t] detections of frame t (a frame-sharded
+    rank: its own frames' counts, zeros elsewhere); numbering and costs stay those of the whole timelapse.
     Returns device tensors (row_ptr i64 [n_frames*cap+1], col i32, length i16, gap u8, cost i64|None)."""
     n_frames, cap = x.shape
     max_gap = len(dmax)
@@ -285,7 +287,17 @@ def build_arcs(x, y, count, H, W, dmax, cost_units=None, mask=None, max_dist=MAX
     head += (row_ptr.data_ptr(), work.data_ptr())
 
     def call(col, length, gap, cu, cost, what):
-        if length_table is not None:
+        if src_count is not None:
+            assert length_table is None
+            v = vis or {}
+            rc = lib.axt_build_arcs_rows(x.data_ptr(), y.data_ptr(), count.data_ptr(), src_count.data_ptr(), n_frames, cap,
+                                         mask._h if mask is not None else None, H, W, int(max_dist), int(bool(conn8)), max_gap,
+                                         h_dmax.ctypes.data, v['hist'].data_ptr() if vis else None,
+                                         v['hsum'].data_ptr() if vis else None, float(v.get('weight', 0.0)),
+                                         float(v.get('miss_rate', 0.0)), float(v.get('thr', 0.0)), row_ptr.data_ptr(),
+                                         work.data_ptr(), _lib.dptr(col), _lib.dptr(length), _lib.dptr(gap), _lib.dptr(cu),
+                                         _lib.dptr(cost), ctypes.byref(n_arcs), _stream())
+        elif length_table is not None:
             rc = lib.axt_build_arcs_from_lengths(length_table.data_ptr(), x.data_ptr(), y.data_ptr(), count.data_ptr(), n_frames,
                                                  cap, int(max_dist), max_gap, h_dmax.ctypes.data, row_ptr.data_ptr(),
                                                  work.data_ptr(), _lib.dptr(col), _lib.dptr(length), _lib.dptr(gap),

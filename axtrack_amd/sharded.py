@@ -1,10 +1,11 @@
 """Frame sharding across the GPUs of one node (one process per GPU, torch.distributed).
 
 Detection is embarrassingly parallel over frames: rank r owns a contiguous block of detection
-frames and reads a +-2-frame input halo; no communication. Association is global, so the only
-exchange on the path is ONE all-gather of the per-frame detection lists (a few MB: latency-bound;
-RCCL over xGMI on GPUs, gloo on CPU in the tests). Every rank then holds all detections and runs
-the same deterministic integer-cost solve (replicated: no broadcast needed).
+frames and reads a +-2-frame input halo; no communication. Association is global: ONE all-gather of the
+per-frame detection lists (a few MB: latency-bound; RCCL over xGMI on GPUs, gloo on CPU in the tests) gives every
+rank all detections. The per-frame work of the association stays sharded -- the Hungarian variant's frame pairs
+(one MAX all-reduce joins the links), the flow tracker's arc rows with their path searches (all_gather_arcs) -- and
+only the deterministic integer-cost flow solve is replicated (a unique optimum: no broadcast needed).
 """
 import torch
 import torch.distributed as dist
@@ -33,6 +34,36 @@ def all_gather_detections(conf, x, y, count, group=None):
     g_y = out[:, 2 * cap:3 * cap].contiguous()
     g_count = out[:, 3 * cap].contiguous()
     return g_conf, g_x, g_y, g_count
+
+
+def all_gather_arcs(row_ptr, col, length, gap, cost, n_det, group=None):
+    """Every rank has built the arc rows of its own frames (hotpath.build_arcs(src_count=...): row_ptr covers all n_det
+    detections, rows of other ranks' frames are empty). Returns the arc list of the whole timelapse on every rank --
+    the ranks' lists in rank order, which is row order because the frame blocks are contiguous. Two collectives: a SUM
+    all-reduce of the per-row counts (with the list lengths in its tail) and one all-gather of the arcs, packed as two
+    i64 words each (cost | col, length, gap) and padded to the longest list."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = col.device
+    n = int(col.numel())
+    counts = torch.zeros((n_det + world,), dtype=torch.int64, device=dev)
+    counts[:n_det] = row_ptr[1:n_det + 1] - row_ptr[:n_det]
+    counts[n_det + rank] = n
+    dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+    sizes = counts[n_det:].tolist()
+    longest = max(max(sizes), 1)
+    packed = torch.zeros((longest, 2), dtype=torch.int64, device=dev)
+    packed[:n, 0] = cost
+    packed[:n, 1] = col.to(torch.int64) | (length.to(torch.int64) << 32) | (gap.to(torch.int64) << 48)
+    out = torch.empty((world * longest, 2), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(out, packed, group=group)
+    parts = [out[r * longest:r * longest + sizes[r]] for r in range(world)]
+    allp = torch.cat(parts, dim=0)
+    g_row_ptr = torch.zeros((n_det + 1,), dtype=torch.int64, device=dev)
+    g_row_ptr[1:] = torch.cumsum(counts[:n_det], 0)
+    w = allp[:, 1]
+    return (g_row_ptr, (w & 0xffffffff).to(torch.int32), ((w >> 32) & 0xffff).to(torch.int16),
+            ((w >> 48) & 0xff).to(torch.uint8), allp[:, 0].contiguous())
 
 
 def assemble_ided_dets_all(blocks, n_frames, reproduce_label_quirk=True):

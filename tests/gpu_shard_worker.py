@@ -20,13 +20,14 @@ def run(rank, world, port, q, total_frames, seed):
     frames = synth.synth_frames(total_frames + 4, 512, 512, seed=seed, t_range=(f0, f0 + per + 4))
     model = axtrack_amd.Detector(synth.synth_state_dict(42), max_batch=per)
     tl = axtrack_amd.Timelapse(frames, name='shard')
+    tl_masked = axtrack_amd.Timelapse(frames, name='shard', mask=synth.corridor_mask(512, 512, width=40, pitch=128))
     out = {}
-    for mode in ('hungarian', 'mcf', 'mcf+appearance'):
+    for mode in ('hungarian', 'mcf', 'mcf+appearance', 'mcf+mask'):
         P = params.load_parameters()
         P['ASSOCIATION'] = mode.split('+')[0]
-        if '+' in mode:
+        if mode.endswith('appearance'):
             P['MCF_VIS_SIM_WEIGHT'] = 0.2          # the histograms need the pixels: they travel with the detections
-        ad = axtrack_amd.AxonDetections(model, tl, P, None)
+        ad = axtrack_amd.AxonDetections(model, tl_masked if mode.endswith('mask') else tl, P, None)
         ad.detect_dataset()
         ad.gather_detections()
         ad.assign_ids()

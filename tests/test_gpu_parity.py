@@ -531,8 +531,10 @@ def test_full_size_properties_c5_share(weights):
 
 # ----------------------------------------------------------------------------------------- multi-GPU path
 def test_two_rank_frame_sharding(weights):
-    """Two ranks (gloo, both on cuda:0) each detect half of the frames, all-gather the detections and run the
-    replicated association: both must equal the single-process result bit for bit, in both association modes."""
+    """Two ranks (gloo, both on cuda:0) each detect half of the frames, all-gather the detections, build the arcs /
+    solve the frame pairs of their own frames, exchange them and finish the association: both must equal the
+    single-process result bit for bit, in every association mode (Hungarian, flow, flow + appearance, flow on a
+    masked grid)."""
     import socket
     import torch.multiprocessing as mp
     import gpu_shard_worker
@@ -550,12 +552,17 @@ def test_two_rank_frame_sharding(weights):
         p.join(timeout=60)
         assert p.exitcode == 0
     frames = synth.synth_frames(total + 4, 512, 512, seed=seed)
-    for mode in ('hungarian', 'mcf', 'mcf+appearance'):
+    import axtrack_amd
+    for mode in ('hungarian', 'mcf', 'mcf+appearance', 'mcf+mask'):
         P = params.load_parameters()
         P['ASSOCIATION'] = mode.split('+')[0]
-        if '+' in mode:
+        if mode.endswith('appearance'):
             P['MCF_VIS_SIM_WEIGHT'] = 0.2
-        ad = _run_inference(frames, weights, P, name='shard')
+        if mode.endswith('mask'):                # path searches on a masked grid: every rank its own frames' sources
+            tl = axtrack_amd.Timelapse(frames, name='shard', mask=synth.corridor_mask(512, 512, width=40, pitch=128))
+            ad = axtrack_amd.inference(tl, axtrack_amd.Detector(weights, max_batch=32), None, P, None, None, None)
+        else:
+            ad = _run_inference(frames, weights, P, name='shard')
         ref = (ad.n_ids, ad._track_flat.tobytes(), ad.IDed_dets_all.to_numpy().tobytes(), list(ad.IDed_dets_all.index))
         for r in (0, 1):
             assert res[r][mode][:4] == ref, mode          # the table assembled from the two blocks is the global one

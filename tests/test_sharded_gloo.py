@@ -45,6 +45,20 @@ def _worker(rank, world, port, q):
                     for a, b in zip(all_dets, dets))
     P = dict(orc.DEFAULTS, MCF_MIN_FLOW=1)
     row_ptr, col, length, gap, cost, offs = csr_arcs_from_oracle(all_dets, int(g['H']), int(g['W']), P)
+    # sharded arc build: every rank holds the rows of its own frames, all_gather_arcs must rebuild the global list
+    n_det = int(offs[-1])
+    lo, hi = int(offs[start]), int(offs[start + per])
+    a0, a1 = int(row_ptr[lo]), int(row_ptr[hi])
+    local_ptr = np.zeros(n_det + 1, np.int64)
+    local_ptr[lo:hi + 1] = row_ptr[lo:hi + 1] - a0
+    local_ptr[hi + 1:] = a1 - a0
+    g_ptr, g_col, g_len, g_gap, g_cost = sharded.all_gather_arcs(
+        torch.from_numpy(local_ptr), torch.from_numpy(np.ascontiguousarray(col[a0:a1], np.int32)),
+        torch.from_numpy(np.ascontiguousarray(length[a0:a1], np.int16)), torch.from_numpy(np.ascontiguousarray(gap[a0:a1], np.uint8)),
+        torch.from_numpy(np.ascontiguousarray(cost[a0:a1], np.int64)), n_det)
+    ok_gather = ok_gather and (np.array_equal(g_ptr.numpy(), row_ptr[:n_det + 1]) and np.array_equal(g_col.numpy(), col)
+                               and np.array_equal(g_len.numpy(), length) and np.array_equal(g_gap.numpy(), gap)
+                               and np.array_equal(g_cost.numpy(), cost) and len(col) > 0)
     obs_i, en_i, ex_i, _ = node_costs_from_oracle(all_dets, P)
     nxt, track, n_tracks, total = hp.mcf_solve(obs_i, en_i, ex_i, row_ptr, col, cost, 1, 450)
     q.put((rank, ok_gather, n_tracks, total, track.tobytes()))
