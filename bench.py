@@ -48,7 +48,7 @@ def main():
                          "'mcf' = the reference's global min-cost-flow tracker")
     ap.add_argument('--frames', type=int, default=256, help='input frames per GPU (T_all)')
     ap.add_argument('--size', type=int, default=512)
-    ap.add_argument('--cpu-frames', type=int, default=64, help='detection frames of the CPU-baseline sample (0 = skip)')
+    ap.add_argument('--cpu-frames', type=int, default=128, help='detection frames of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--no-profile', action='store_true', help='do not bracket kernels with HIP events')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='gloo only for rehearsals')
     ap.add_argument('--single-device', action='store_true',
