@@ -529,6 +529,44 @@ def test_full_size_properties_c5_share(weights):
     assert np.array_equal(ad2._track_flat, ad._track_flat) and ad2.mcf_total_cost == ad.mcf_total_cost
 
 
+def test_masked_path_lengths_on_a_mask_with_many_components():
+    """More than 64 components: the grid keeps no per-component off-cell fields and the arc builder resolves targets
+    in other components with the general search instead of the windowed one -- same path lengths as the oracle."""
+    H, W = 208, 224
+    mask = np.zeros((H, W), bool)
+    for r in range(9):
+        for c in range(9):
+            mask[8 + r * 22:8 + r * 22 + 14, 8 + c * 24:8 + c * 24 + 16] = True      # 81 islands
+    rng = np.random.default_rng(4)
+    ys, xs = np.nonzero(mask)
+    F, cap = 3, 16
+    dets = []
+    for t in range(F):
+        k = rng.choice(len(ys), 10, replace=False)
+        px, py = xs[k].copy(), ys[k].copy()
+        px[:2] = rng.integers(0, W, 2); py[:2] = rng.integers(0, H, 2)               # two anywhere
+        dets.append((np.sort(rng.uniform(0.6, 1.0, 10).astype(np.float32))[::-1], px.astype(np.int64), py.astype(np.int64)))
+    x = np.zeros((F, cap), np.int32); y = np.zeros((F, cap), np.int32)
+    for t, d in enumerate(dets):
+        x[t, :10] = d[1]; y[t, :10] = d[2]
+    cnt = np.full(F, 10, np.int32)
+    from axtrack_amd.detections import transition_cost_table
+    table, dmax = transition_cost_table(params.DEPLOYED)
+    units = np.where(np.isfinite(table), np.rint(table * 1e6), 0).astype(np.int64)
+    row_ptr, col, length, gap, cost = hp.build_arcs(dev(x), dev(y), dev(cnt), H, W, dmax, units, hp.Grid(mask, False), 500, False)
+    row_ptr, col, length, gap = (v.cpu().numpy() for v in (row_ptr, col, length, gap))
+    got = {(a, int(col[e])): int(length[e]) for a in range(30) for e in range(row_ptr[a], row_ptr[a + 1])}
+    want = {}
+    for t in range(F):
+        for g in (1, 2):
+            if t + g >= F:
+                continue
+            D = orc.path_matrix(dets[t], dets[t + g], H, W, mask, 500, False)
+            for i, j in zip(*np.nonzero(D <= dmax[g - 1])):
+                want[(t * 10 + int(i), (t + g) * 10 + int(j))] = int(D[i, j])
+    assert got == want and len(want) > 50
+
+
 # ----------------------------------------------------------------------------------------- multi-GPU path
 def test_two_rank_frame_sharding(weights):
     """Two ranks (gloo, both on cuda:0) each detect half of the frames, all-gather the detections, build the arcs /
