@@ -238,7 +238,7 @@ def cpu_baseline(args, sd, synth):
     from oracle import oracle as orc
     n = args.cpu_frames
     cores = min(len(os.sched_getaffinity(0)), 16)          # a one-GPU box's CPU share
-    os.environ['OMP_NUM_THREADS'] = str(cores)
+    orc.set_threads(cores)                                 # (the environment variable is read too early to matter here)
     frames = synth.synth_frames(args.frames, args.size, args.size, seed=0, t_range=(0, n + 4))
     Pc = dict(orc.DEFAULTS, MCF_MIN_FLOW=1)
     t = time.perf_counter()

@@ -18,6 +18,20 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* Number of threads of the parallel loops below. The environment variable is only read when the OpenMP runtime starts,
+ * which in a process that has imported torch happened long ago (with one thread per visible CPU). */
+void orc_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n >= 1) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 
 /* ------------------------------------------------------------------------------------
  * CNNBlock.forward: Conv2d(3x3, pad 1, bias) -> BatchNorm2d(eval, eps 1e-5) -> LeakyReLU(0.1)

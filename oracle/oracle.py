@@ -44,7 +44,14 @@ def lib():
         _LIB = ctypes.CDLL(so)
         _LIB.orc_mcf_ssp.restype = ctypes.c_int
         _LIB.orc_astar_len.restype = ctypes.c_int
+        # one thread per visible CPU is what the OpenMP runtime picks; a one-GPU box shows 256 CPUs and grants 16
+        _LIB.orc_set_threads(min(len(os.sched_getaffinity(0)), 16))
     return _LIB
+
+
+def set_threads(n):
+    """Threads of the C restatement's parallel loops (OMP_NUM_THREADS is only read when the OpenMP runtime starts)."""
+    lib().orc_set_threads(int(n))
 
 
 def _p(a, t=ctypes.c_void_p):
@@ -57,7 +64,7 @@ def cnn_forward(sd, X, n_threads=None):
     from axtrack_amd import synth
     L = lib()
     if n_threads:
-        os.environ['OMP_NUM_THREADS'] = str(n_threads)
+        set_threads(n_threads)
     x = np.ascontiguousarray(X, np.float32)
     B, C, H, W = x.shape
     for name, (ci, co, stride, pool) in zip(synth.conv_block_names(), synth.conv_layer_specs()):
