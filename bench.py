@@ -48,7 +48,7 @@ def main():
                          "'mcf' = the reference's global min-cost-flow tracker")
     ap.add_argument('--frames', type=int, default=256, help='input frames per GPU (T_all)')
     ap.add_argument('--size', type=int, default=512)
-    ap.add_argument('--cpu-frames', type=int, default=128, help='detection frames of the CPU-baseline sample (0 = skip)')
+    ap.add_argument('--cpu-frames', type=int, default=252, help='detection frames of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--no-profile', action='store_true', help='do not bracket kernels with HIP events')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='gloo only for rehearsals')
     ap.add_argument('--single-device', action='store_true',
@@ -236,7 +236,7 @@ def committed_traffic(kernel_name):
 def cpu_baseline(args, sd, synth):
     """The CPU oracle on the first `cpu_frames` detection frames of the same timelapse."""
     from oracle import oracle as orc
-    n = args.cpu_frames
+    n = min(args.cpu_frames, args.frames - 4)
     cores = min(len(os.sched_getaffinity(0)), 16)          # a one-GPU box's CPU share
     orc.set_threads(cores)                                 # (the environment variable is read too early to matter here)
     frames = synth.synth_frames(args.frames, args.size, args.size, seed=0, t_range=(0, n + 4))
@@ -248,7 +248,7 @@ def cpu_baseline(args, sd, synth):
         orc.detect_dataset(frames, sd)
     dt = time.perf_counter() - t
     return {'value': round(n / dt, 3), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
-            'sample': f'first {n} detection frames of the same synthetic timelapse ({dt:.1f} s of CPU work), '
+            'sample': f'{"all" if n == args.frames - 4 else "first"} {n} detection frames of the same synthetic timelapse ({dt:.1f} s of CPU work), '
                       f'oracle/ (C + numpy restatement, OpenMP x{cores})'}
 
 
