@@ -284,6 +284,16 @@ def test_full_size_properties(weights, T_all, size, name):
     ad2 = _run_inference(frames, weights, P, name=name)
     assert np.array_equal(ad2._track_flat, ad._track_flat) and ad2.mcf_total_cost == ad.mcf_total_cost
     assert torch.equal(ad2._yolo, ad._yolo)
+    if name == 'c3':
+        # and at this size against the oracle: detection lists of all 252 frames bit-exact given the same YOLO grids, and
+        # the frame-to-frame association identical (the flow solve at this size is compared on the CPU:
+        # tests/test_host_logic.py::test_flow_solver_fast_and_general_paths_agree_at_full_size)
+        ah = _run_inference(frames, weights, dict(P, ASSOCIATION='hungarian'), name=name)
+        ref = orc.inference(frames, weights, P=orc.DEFAULTS, yolo=list(ah._yolo.cpu().numpy()), assoc='hungarian')
+        for t, (rc, rx, ry) in enumerate(ref['dets']):
+            n = len(rc)
+            assert cnt[t] == n and np.array_equal(conf[t, :n], rc) and np.array_equal(x[t, :n], rx) and np.array_equal(y[t, :n], ry)
+        assert tracks_from_next(np.zeros(len(ah._track_flat)), ah._track_flat, ah._offs) == ref['trajs']
 
 
 # ----------------------------------------------------------------------------------------- config 3 variant

@@ -160,8 +160,8 @@ def test_mcf_infeasible_and_argument_errors():
 def test_flow_solver_fast_and_general_paths_agree_at_full_size(monkeypatch):
     """The detections of the C3 bench timelapse (252 frames, 19 340 detections, captured from the GPU path into
     tests/data/c3_dets.npz): the assignment-form solver and the successive-shortest-path solver must return the same
-    optimum and the same trajectories on the full 553 k-arc network, and so must the assignment solver at any number
-    of threads."""
+    optimum and the same trajectories on the full 553 k-arc network, so must the assignment solver at any number of
+    threads, and all of them the oracle's own solver on the oracle's own network."""
     from axtrack_amd.detections import transition_cost_table, _arc_cost_int_vec
     d = np.load(os.path.join(ROOT, 'tests', 'data', 'c3_dets.npz'))
     cnt = d['count']
@@ -202,6 +202,10 @@ def test_flow_solver_fast_and_general_paths_agree_at_full_size(monkeypatch):
         monkeypatch.setenv('AXT_MCF_THREADS', threads)
         par = hp.mcf_solve(obs_i, en_i, ex_i, row_ptr, b, cost, 5, 450)
         assert par[2] == fast[2] and par[3] == fast[3] and np.array_equal(par[0], fast[0]) and np.array_equal(par[1], fast[1])
+    # the oracle's own network and solver (Bellman-Ford successive shortest paths, ~35 s) at this size
+    dets = [(d['conf'][t, :cnt[t]], X[t], Y[t]) for t in range(F)]
+    trajs, total = orc.mcf_solve(dets, orc.all_path_matrices(dets, 512, 512), dict(orc.DEFAULTS))
+    assert total == fast[3] and tracks_from_next(fast[0], fast[1], offs) == trajs
     monkeypatch.setenv('AXT_MCF_FORCE_SSP', '1')
     slow = hp.mcf_solve(obs_i, en_i, ex_i, row_ptr, b, cost, 5, 450)
     assert fast[2] == slow[2] == 63 and fast[3] == slow[3]
