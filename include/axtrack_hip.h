@@ -222,8 +222,9 @@ int axt_build_arcs_vis(const int32_t *d_x, const int32_t *d_y, const int32_t *d_
                        double edge_cost_thr, int64_t *d_row_ptr, int32_t *d_work, int32_t *d_col, int16_t *d_len,
                        uint8_t *d_gap, int64_t *d_cost, int64_t *n_arcs, void *stream);
 
-/* The same arc builder for a frame-sharded run (one process per GPU after the all-gather of the detections,
- * SURVEY.md section 8e): rows are built only for the first d_src_count[t] detections of every frame t -- a rank passes
+/* The same arc builder (_compute_detections_astar_paths + transition_model + the tracker's edge admission,
+ * AxonDetections.py:526-629,663-690, mincostflow_models.py:67-119) for a frame-sharded run (one process per GPU after
+ * the all-gather of the detections): rows are built only for the first d_src_count[t] detections of every frame t -- a rank passes
  * its own frames' counts and zeros elsewhere -- while targets, detection numbering and integer costs are those of the
  * whole timelapse (d_count), so that the ranks' arc lists, concatenated in rank order, are exactly the single-process
  * list. d_hist == NULL: costs from d_cost_units as in axt_build_arcs; otherwise the appearance term as in
@@ -257,8 +258,8 @@ int axt_mcf_solve(int n_det, const int64_t *h_obs, const int64_t *h_entry, const
 
 /* ------------------------------------------------------------------------------------------
  * Frame-to-frame Hungarian association (BASELINE config 3; a build-side variant -- the reference
- * only runs the global tracker above). Same cost model: linking a (frame t) to b (frame t+g)
- * costs transition_model(D(a,b), g) and is admitted for D <= h_dmax[g-1]; leaving a detection
+ * only runs the global tracker above, AxonDetections.py:663-690). Same cost model: linking a (frame t)
+ * to b (frame t+g) costs transition_model(D(a,b), g) (mincostflow_models.py:67-119) and is admitted for D <= h_dmax[g-1]; leaving a detection
  * without successor costs thr_units (= round(MCF_EDGE_COST_THR * 1e6)). Every frame pair
  * (t,t+1) is solved exactly and independently (one wavefront each), then (t,t+2) among the
  * detections left unlinked, then chains are numbered by (first frame, index).
@@ -271,7 +272,8 @@ int axt_hungarian_assoc(const int32_t *d_x, const int32_t *d_y, const int32_t *d
                         const int64_t *d_cost_units, int64_t thr_units, int32_t *d_work,
                         int32_t *d_track, int32_t *d_n_tracks, void *stream);
 
-/* The two halves of axt_hungarian_assoc, for frame-sharded runs: every rank solves the frame pairs of its own
+/* The two halves of axt_hungarian_assoc (same cost model, mincostflow_models.py:67-119; stands where the reference
+ * runs its tracker, AxonDetections.py:663-690), for frame-sharded runs: every rank solves the frame pairs of its own
  * source frames [t_begin, t_end) into d_pred = pred1 | pred2 (i32 [2, n_frames*cap], predecessor index in frame
  * t-1 / t-2 or -1; entries of other ranks' frames stay -1), the ranks combine d_pred with one element-wise MAX
  * all-reduce, then each numbers the chains. d_work: i32 [2*n_frames*cap + n_frames + 1] for the pairs,
@@ -311,7 +313,8 @@ int axt_detection_confusion(const float *d_conf, const int32_t *d_x, const int32
                             int gcap, const double *d_thrs, int n_thr, int min_dist, int k_mask,
                             int32_t *d_confusion, uint8_t *d_fp_mask, uint8_t *d_fn_mask, void *stream);
 
-/* Integer arc cost used by the flow network: round(cost * 1e6) << 16 | hash16(kind, a, b).
+/* Integer arc cost used by the flow network (the costs libmot hands its solver at AxonDetections.py:663-690, from
+ * observation_model / transition_model, mincostflow_models.py:6-27,67-119): round(cost * 1e6) << 16 | hash16(kind, a, b).
  * kind 0 entry, 1 exit, 2 observation, 3 transition. The low 16 bits make the optimum unique
  * (DESIGN.md "Unpinned third-party semantics"). */
 int64_t axt_arc_cost_int(double cost, int kind, int64_t a, int64_t b);
