@@ -214,6 +214,9 @@ struct axt_grid {
     unsigned char *d_off = nullptr;
     int n_comp = 0;
     bool has_fields = false;             // d_off covers every component (trivially so for an empty mask)
+    // [n_comp][4 or 8][H][Ww] bit rows: bit x of row y of direction d is set iff stepping INTO (y,x) from its
+    // neighbour (y+oy[d], x+ox[d]) keeps the off-cell count minimal: d_off[A][(y,x)] == d_off[A][neighbour] + [cell off]
+    unsigned int *d_tight = nullptr;
 };
 
 namespace {
@@ -235,7 +238,8 @@ constexpr int BFS_THREADS = 1024;      // one workgroup per CU (LDS-bound): many
 __global__ __launch_bounds__(BFS_THREADS) void mask_bfs_kernel(
     const int *__restrict__ x, const int *__restrict__ y, const int *__restrict__ count, const int *__restrict__ src_count,
     int n_frames, int cap, const unsigned int *__restrict__ bits, const int *__restrict__ label, int H, int W, int Ww,
-    int conn8, int max_dist, int max_gap, const int *__restrict__ dmax, short *__restrict__ Dtmp)
+    int conn8, int max_dist, int max_gap, const int *__restrict__ dmax, short *__restrict__ Dtmp,
+    const unsigned int *__restrict__ tight)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned int bsm[];
     unsigned int *A = bsm, *Bm = A + BFS_WH * BFS_WW, *M = Bm + BFS_WH * BFS_WW;
@@ -253,6 +257,15 @@ __global__ __launch_bounds__(BFS_THREADS) void mask_bfs_kernel(
     int depth = 0;
     for (int g = 0; g < max_gap; ++g) depth = max(depth, dmax[g] - 1);
     depth = min(depth, BFS_R);
+    // A source ON the mask (component A) knows the fewest off-mask cells k(c) = d_off[A][c] of every cell, and the
+    // minimum-cost paths are exactly the paths along which k grows by [cell off the mask] at every step ("tight"
+    // steps: a prefix of an optimal path is optimal). Their fewest moves is a plain breadth-first search over tight
+    // steps -- the same bit-parallel sweep, with one precomputed bit row per direction (axt_grid::d_tight) in place of
+    // the mask -- and it serves every target, in whatever component or off the mask.
+    const int ls_src = s_in ? label[(long)sy * W + sx] : 0;
+    const bool tight_mode = tight != nullptr && ls_src > 0;
+    const int ndir = conn8 ? 8 : 4;
+    const unsigned int *tg = tight_mode ? tight + (long)(ls_src - 1) * ndir * H * Ww : nullptr;
 
     // ---- source labels
     if (tid == 0) {
@@ -300,7 +313,7 @@ __global__ __launch_bounds__(BFS_THREADS) void mask_bfs_kernel(
                 if (dx == 0 && dy == 0) res = 1;
                 else {
                     const int lt = label[(long)ty * W + tx];
-                    bool level0 = false;
+                    bool level0 = tight_mode;
                     for (int k = 0; k < n_slab; ++k) level0 |= (lt != 0 && s_labels[k] == lt);
                     if (level0) { pos = (ty - wy0) * (BFS_WW * 32) + (tx - wx0); atomicAdd(&n_open, 1); }
                     else res = -1;                                    // exact search decides
@@ -331,6 +344,29 @@ __global__ __launch_bounds__(BFS_THREADS) void mask_bfs_kernel(
             const int r = rlo + rr, w = wlo + (e - rr * nw);
             const unsigned int *row = cur + r * BFS_WW;
             unsigned int v;
+            if (tight_mode) {
+                v = row[w];
+                const int gy = wy0 + r, gw = (wx0 >> 5) + w;
+                if (gy >= 0 && gy < H && gw >= 0 && gw < Ww) {
+                    const unsigned int *tw = tg + (long)gy * Ww + gw;
+                    const long dstride = (long)H * Ww;
+                    const int oy8[8] = {-1, 1, 0, 0, -1, -1, 1, 1}, ox8[8] = {0, 0, -1, 1, -1, 1, -1, 1};
+                    for (int d = 0; d < ndir; ++d) {
+                        const int rp = r + oy8[d];
+                        if (rp < 0 || rp >= BFS_WH) continue;
+                        const unsigned int *prow = cur + rp * BFS_WW;
+                        const unsigned int c0 = prow[w];
+                        unsigned int from;
+                        if (ox8[d] < 0) from = (c0 << 1) | (w > 0 ? prow[w - 1] >> 31 : 0u);
+                        else if (ox8[d] > 0) from = (c0 >> 1) | (w + 1 < BFS_WW ? prow[w + 1] << 31 : 0u);
+                        else from = c0;
+                        if (from) v |= from & tw[d * dstride];
+                    }
+                }
+                nxt[r * BFS_WW + w] = v;
+                changed |= (v != row[w]);
+                continue;
+            }
             if (conn8) {
                 v = dil_h(row, w);
                 if (r > 0) v |= dil_h(row - BFS_WW, w);
@@ -576,10 +612,39 @@ extern "C" int axt_grid_create(const uint8_t *h_mask, int H, int W, int conn8, a
         }
     }
     g->has_fields = next == 0 || !off.empty();
+    std::vector<unsigned int> tightv;
+    if (!off.empty()) {
+        const int Ww = g->Ww;
+        const int oy8[8] = {-1, 1, 0, 0, -1, -1, 1, 1}, ox8[8] = {0, 0, -1, 1, -1, 1, -1, 1};
+        tightv.assign((size_t)next * nn * H * Ww, 0u);
+        for (int L = 0; L < next; ++L) {
+            const unsigned char *o = off.data() + (size_t)L * H * W;
+            for (int d = 0; d < nn; ++d) {
+                unsigned int *tb = tightv.data() + ((size_t)L * nn + d) * H * Ww;
+                for (int yy = 0; yy < H; ++yy) {
+                    const int py = yy + oy8[d];
+                    if (py < 0 || py >= H) continue;
+                    for (int xx = 0; xx < W; ++xx) {
+                        const int px = xx + ox8[d];
+                        if (px < 0 || px >= W) continue;
+                        const int kc = o[(size_t)yy * W + xx], kp = o[(size_t)py * W + px];
+                        if (kc < 255 && kp < 255 && kc == kp + (m01[(size_t)yy * W + xx] ? 0 : 1))
+                            tb[(size_t)yy * Ww + (xx >> 5)] |= 1u << (xx & 31);
+                    }
+                }
+            }
+        }
+    }
     int rc = AXT_OK;
     if (!off.empty() && (hipMalloc((void **)&g->d_off, off.size()) != hipSuccess ||
                          hipMemcpy(g->d_off, off.data(), off.size(), hipMemcpyHostToDevice) != hipSuccess)) {
         axt_set_error("axt_grid_create: device allocation for the component distance fields failed");
+        axt_grid_destroy(g);
+        return AXT_ENOMEM;
+    }
+    if (!tightv.empty() && (hipMalloc((void **)&g->d_tight, tightv.size() * 4) != hipSuccess ||
+                            hipMemcpy(g->d_tight, tightv.data(), tightv.size() * 4, hipMemcpyHostToDevice) != hipSuccess)) {
+        axt_set_error("axt_grid_create: device allocation for the tight-step rows failed");
         axt_grid_destroy(g);
         return AXT_ENOMEM;
     }
@@ -605,6 +670,7 @@ extern "C" void axt_grid_destroy(axt_grid *g)
     (void)hipFree(g->d_bits);
     (void)hipFree(g->d_label);
     (void)hipFree(g->d_off);
+    (void)hipFree(g->d_tight);
     delete g;
 }
 
@@ -625,7 +691,7 @@ int axt_masked_distance_table(const axt_grid *g, const int32_t *d_x, const int32
         attr = true;
     }
     hipLaunchKernelGGL(mask_bfs_kernel, dim3(cap, n_frames), dim3(BFS_THREADS), lds, st, d_x, d_y, d_count, d_src_count, n_frames, cap, g->d_bits,
-                       g->d_label, g->H, g->W, g->Ww, g->conn8, max_dist, max_gap, d_dmax, d_Dtmp);
+                       g->d_label, g->H, g->W, g->Ww, g->conn8, max_dist, max_gap, d_dmax, d_Dtmp, (const unsigned int *)g->d_tight);
     AXT_LAUNCH_CHECK();
     int *flags = nullptr, *n_flagged = nullptr;
     AXT_CHECK_HIP(hipMallocAsync((void **)&flags, sizeof(int) * ((size_t)n_frames * cap + 1), st));

@@ -175,12 +175,12 @@ int axt_path_cells(const int32_t *d_xa, const int32_t *d_ya, int na,
  * Optional integer arc costs: d_cost_units i64 [max_gap, max_dist+1] holds round(cost*1e6) of
  * transition_model for every (gap, D); d_cost i64 [n_arcs] then receives
  * axt_arc_cost_int-compatible values (units << 16 | hash16(3, a, b)). Both NULL to skip.
- * grid = NULL: all-ones mask, closed-form path lengths. With a grid, path lengths come from one bit-parallel
- * breadth-first search per detection over the on-mask cells (depth h_dmax-1 <= 250 moves; connected components
- * decide which targets that search can reach) and, for targets in other components or off the mask, from a
- * label-correcting search on (off-mask cells, moves) inside the window paths of <= dmax cells cannot leave, checked
- * against the per-component off-cell counts the grid holds (masks with more than 64 components: the exact search of
- * axt_path_cost). */
+ * grid = NULL: all-ones mask, closed-form path lengths. With a grid the minimum-cost paths are ordered by (off-mask
+ * cells entered, moves); the grid holds, per connected component of the mask, the fewest off-mask cells to every cell.
+ * A detection on the mask gets all its path lengths from one bit-parallel breadth-first search (depth h_dmax-1 <= 250
+ * moves) over the steps that keep that count minimal; a detection off the mask from a label-correcting search on
+ * (off-mask cells, moves) inside the window paths of <= dmax cells cannot leave, checked against the same counts
+ * (masks with more than 64 components: on-mask search within the component + the exact search of axt_path_cost). */
 int axt_build_arcs(const int32_t *d_x, const int32_t *d_y, const int32_t *d_count, int n_frames, int cap,
                    const axt_grid *grid, int H, int W, int max_dist, int conn8,
                    int max_gap, const int32_t *h_dmax,
