@@ -714,7 +714,7 @@ int axt_masked_distance_table(const axt_grid *g, const int32_t *d_x, const int32
                 for (int i = 0; i < hc[t] && i < cap; ++i)
                     if (hf[(size_t)t * cap + i]) tasks.push_back(t * cap + i);
             const int n_tasks = (int)tasks.size();
-            if (getenv("AXT_PATH_DEBUG")) fprintf(stderr, "masked arcs: %d sources with targets in other components (windowed search)\n", n_tasks);
+            if (getenv("AXT_PATH_DEBUG")) fprintf(stderr, "masked arcs: %d sources off the mask or without component fields (windowed search)\n", n_tasks);
             const int wgs = n_tasks < 512 ? n_tasks : 512;       // two per CU; more only thrash the caches (measured)
             int *d_tasks = nullptr;
             unsigned char *scratch = nullptr;
