@@ -81,7 +81,8 @@ __global__ __launch_bounds__(64) void hungarian_pair_kernel(
     const int *__restrict__ frame_off, int n_frames, int cap, int H, int W, int max_dist, int conn8,
     int dmax, const long *__restrict__ units, long thr_units,
     const int *__restrict__ succ1, const int *__restrict__ pred1,
-    int *__restrict__ succ_out, int *__restrict__ pred_out, int cdim, int t_first)
+    int *__restrict__ succ_out, int *__restrict__ pred_out, int cdim, int t_first,
+    const short *__restrict__ dtab, int tab_gaps)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
     const int t = t_first + blockIdx.x, tb = t + GAP, lane = threadIdx.x;
@@ -122,7 +123,13 @@ __global__ __launch_bounds__(64) void hungarian_pair_kernel(
     // cost of linking row i to column j (HINF: not admitted)
     auto link_cost = [&](int i, int j) -> long {
         if (!col_ok[j]) return HINF;
-        const int d = h_path_len_open(xr[i], yr[i], xs[j], ys[j], H, W, max_dist, conn8);
+        int d;
+        if (dtab) {                          // masked grid: path lengths from the arc builder's searches (<= 0: none)
+            d = dtab[(((long)t * cap + i) * tab_gaps + (GAP - 1)) * cap + j];
+            if (d <= 0) return HINF;
+        } else {
+            d = h_path_len_open(xr[i], yr[i], xs[j], ys[j], H, W, max_dist, conn8);
+        }
         return d <= dmax ? h_arc_cost_int(lunits[d], 3, a0 + i, b0 + j) : HINF;
     };
 
@@ -441,10 +448,23 @@ int axt_frame_offsets(const int32_t *d_count, int n_frames, int cap, int32_t *d_
 // (predecessor index in frame t-1 / t-2, or -1). Frame-sharded runs give every rank its own range and combine the
 // arrays with one element-wise MAX all-reduce (entries not owned stay -1; the one redundant boundary pair is
 // deterministic, so equal on both ranks). d_work i32 [2*n_frames*cap + n_frames + 1].
-extern "C" int axt_hungarian_pairs(const int32_t *d_x, const int32_t *d_y, const int32_t *d_count, int n_frames, int cap,
-                                   int H, int W, int max_dist, int conn8, int max_gap, const int32_t *h_dmax,
-                                   const int64_t *d_cost_units, int64_t thr_units, int t_begin, int t_end,
-                                   int32_t *d_pred, int32_t *d_work, void *stream)
+struct axt_grid;
+int axt_masked_distance_table(const axt_grid *g, const int32_t *d_x, const int32_t *d_y, const int32_t *d_count,
+                              const int32_t *d_src_count, int n_frames, int cap, int max_dist, int max_gap,
+                              const int32_t *h_dmax, const int32_t *d_dmax, int16_t *d_Dtmp, hipStream_t st);
+
+namespace {
+__global__ void range_count_kernel(const int *__restrict__ count, int *__restrict__ out, int n, int a, int b)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (i >= a && i < b) ? count[i] : 0;
+}
+}  // namespace
+
+extern "C" int axt_hungarian_pairs_grid(const int32_t *d_x, const int32_t *d_y, const int32_t *d_count, int n_frames, int cap,
+                                        const axt_grid *grid, int H, int W, int max_dist, int conn8, int max_gap,
+                                        const int32_t *h_dmax, const int64_t *d_cost_units, int64_t thr_units, int t_begin,
+                                        int t_end, int32_t *d_pred, int32_t *d_work, void *stream)
 {
     AXT_REQUIRE(d_x && d_y && d_count && h_dmax && d_cost_units && d_work && d_pred, "null argument");
     AXT_REQUIRE(n_frames >= 1 && cap >= 1 && cap <= 2048, "axt_hungarian_pairs: cap %d out of range [1,2048]", cap);
@@ -478,10 +498,24 @@ extern "C" int axt_hungarian_pairs(const int32_t *d_x, const int32_t *d_y, const
     }
     // pass 2 of source frame t needs pass 1 of the pairs (t, t+1) and (t+1, t+2): pass 1 runs one frame further
     const int e1 = (max_gap == 2 ? t_end + 1 : t_end) < n_frames - 1 ? (max_gap == 2 ? t_end + 1 : t_end) : n_frames - 1;
+    // masked grid: the path lengths of the source frames' detections to the next max_gap frames, from the searches of the
+    // arc builder (path_bfs.hip), read by the pair kernels instead of the closed form
+    short *dtab = nullptr;
+    int *aux = nullptr;
+    if (grid && e1 > t_begin) {
+        AXT_CHECK_HIP(hipMallocAsync((void **)&dtab, sizeof(short) * (size_t)n_frames * cap * max_gap * cap, st));
+        AXT_CHECK_HIP(hipMallocAsync((void **)&aux, sizeof(int) * ((size_t)n_frames + max_gap), st));
+        int *src_count = aux, *dmax_dev = aux + n_frames;
+        hipLaunchKernelGGL(range_count_kernel, dim3((n_frames + 255) / 256), dim3(256), 0, st, d_count, src_count, n_frames, t_begin, e1);
+        AXT_LAUNCH_CHECK();
+        AXT_CHECK_HIP(hipMemcpyAsync(dmax_dev, h_dmax, sizeof(int) * max_gap, hipMemcpyHostToDevice, st));
+        rc = axt_masked_distance_table(grid, d_x, d_y, d_count, src_count, n_frames, cap, max_dist, max_gap, h_dmax, dmax_dev, dtab, st);
+        if (rc) return rc;
+    }
     if (e1 > t_begin) {
         hipLaunchKernelGGL((cap <= 192 ? hungarian_pair_kernel<1, 3> : cap <= 576 ? hungarian_pair_kernel<1, 9> : hungarian_pair_kernel<1, 0>), dim3(e1 - t_begin), dim3(64), lds, st, d_x, d_y, d_count, frame_off,
                            n_frames, cap, H, W, max_dist, conn8, h_dmax[0], (const long *)d_cost_units, (long)thr_units,
-                           (const int *)nullptr, (const int *)nullptr, succ1, pred1, cdim, t_begin);
+                           (const int *)nullptr, (const int *)nullptr, succ1, pred1, cdim, t_begin, (const short *)dtab, max_gap);
         AXT_LAUNCH_CHECK();
     }
     const int e2 = t_end < n_frames - 2 ? t_end : n_frames - 2;
@@ -489,10 +523,23 @@ extern "C" int axt_hungarian_pairs(const int32_t *d_x, const int32_t *d_y, const
         hipLaunchKernelGGL((cap <= 192 ? hungarian_pair_kernel<2, 3> : cap <= 576 ? hungarian_pair_kernel<2, 9> : hungarian_pair_kernel<2, 0>), dim3(e2 - t_begin), dim3(64), lds, st, d_x, d_y, d_count, frame_off,
                            n_frames, cap, H, W, max_dist, conn8, h_dmax[1],
                            (const long *)d_cost_units + (max_dist + 1), (long)thr_units, (const int *)succ1,
-                           (const int *)pred1, succ2, pred2, cdim, t_begin);
+                           (const int *)pred1, succ2, pred2, cdim, t_begin, (const short *)dtab, max_gap);
         AXT_LAUNCH_CHECK();
     }
+    if (dtab) {
+        AXT_CHECK_HIP(hipFreeAsync(dtab, st));
+        AXT_CHECK_HIP(hipFreeAsync(aux, st));
+    }
     return AXT_OK;
+}
+
+extern "C" int axt_hungarian_pairs(const int32_t *d_x, const int32_t *d_y, const int32_t *d_count, int n_frames, int cap,
+                                   int H, int W, int max_dist, int conn8, int max_gap, const int32_t *h_dmax,
+                                   const int64_t *d_cost_units, int64_t thr_units, int t_begin, int t_end,
+                                   int32_t *d_pred, int32_t *d_work, void *stream)
+{
+    return axt_hungarian_pairs_grid(d_x, d_y, d_count, n_frames, cap, nullptr, H, W, max_dist, conn8, max_gap, h_dmax,
+                                    d_cost_units, thr_units, t_begin, t_end, d_pred, d_work, stream);
 }
 
 // Chains of links -> trajectory ids numbered by (first frame, index). d_pred as written by axt_hungarian_pairs

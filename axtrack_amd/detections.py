@@ -506,13 +506,12 @@ class AxonDetections(object):
         masked = self.dataset.mask2d is not None
         shard = getattr(self, '_shard', None)           # set by gather_detections(): solve only this rank's frame pairs
         if mode == 'hungarian':
-            if masked:
-                raise NotImplementedError("ASSOCIATION='hungarian' supports all-ones masks only; use 'mcf'")
             track, n_tracks = hp.hungarian_assoc(self.d_x, self.d_y, self.d_count, self.dataset.sizey,
                                                  self.dataset.sizex, dmax, units,
                                                  int(np.rint(P['MCF_EDGE_COST_THR'] * 1e6)),
                                                  self.max_px_assoc_dist, self.conn8,
-                                                 *((shard[0], shard[1]), shard[2]) if shard else ())
+                                                 *(((shard[0], shard[1]), shard[2]) if shard else (None, None)),
+                                                 mask=self._mask_dev() if masked else None)
             self._d_track, self._track_flat_cache = track, None       # host copies are made on first use only
             self.n_ids, self.mcf_total_cost = int(n_tracks.item()), None
             return True

@@ -329,10 +329,11 @@ def build_arcs(x, y, count, H, W, dmax, cost_units=None, mask=None, max_dist=MAX
 
 
 def hungarian_assoc(x, y, count, H, W, dmax, cost_units, thr_units, max_dist=MAX_PX_ASSOC_DIST, conn8=False,
-                    frame_range=None, group=None):
+                    frame_range=None, group=None, mask=None):
     """Frame-to-frame Hungarian association (BASELINE config 3) of a whole timelapse on the GPU.
     frame_range=(a, b): this rank solves only the pairs of source frames a..b-1; the link arrays are then
     combined over `group` with one MAX all-reduce and every rank numbers the chains (frame-sharded runs).
+    mask: None (all-ones) or a Grid: path lengths then come from the masked-grid searches of the arc builder.
     Returns (track i32 [F,cap] device tensor, n_tracks device tensor [1])."""
     n_frames, cap = x.shape
     max_gap = len(dmax)
@@ -347,10 +348,11 @@ def hungarian_assoc(x, y, count, H, W, dmax, cost_units, thr_units, max_dist=MAX
     a, b = (0, n_frames) if frame_range is None else frame_range
     lib = _lib.load()
     with torch.cuda.device(dev):
-        _lib.check(lib.axt_hungarian_pairs(x.data_ptr(), y.data_ptr(), count.data_ptr(), n_frames, cap, H, W,
-                                           int(max_dist), int(bool(conn8)), max_gap, h_dmax.ctypes.data,
-                                           cu.data_ptr(), int(thr_units), int(a), int(b), pred.data_ptr(),
-                                           work.data_ptr(), _stream()), 'axt_hungarian_pairs')
+        _lib.check(lib.axt_hungarian_pairs_grid(x.data_ptr(), y.data_ptr(), count.data_ptr(), n_frames, cap,
+                                                mask._h if mask is not None else None, H, W,
+                                                int(max_dist), int(bool(conn8)), max_gap, h_dmax.ctypes.data,
+                                                cu.data_ptr(), int(thr_units), int(a), int(b), pred.data_ptr(),
+                                                work.data_ptr(), _stream()), 'axt_hungarian_pairs_grid')
         if frame_range is not None:
             import torch.distributed as dist
             dist.all_reduce(pred, op=dist.ReduceOp.MAX, group=group)

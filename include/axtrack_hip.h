@@ -282,6 +282,13 @@ int axt_hungarian_pairs(const int32_t *d_x, const int32_t *d_y, const int32_t *d
                         int H, int W, int max_dist, int conn8, int max_gap, const int32_t *h_dmax,
                         const int64_t *d_cost_units, int64_t thr_units, int t_begin, int t_end,
                         int32_t *d_pred, int32_t *d_work, void *stream);
+/* axt_hungarian_pairs on a masked grid (grid = NULL: identical to it): the path lengths of the pairs come from the
+ * masked-grid searches of the arc builder (_compute_detections_astar_paths on weights {1 on mask, 65536 off},
+ * AxonDetections.py:526-629) instead of the closed form. */
+int axt_hungarian_pairs_grid(const int32_t *d_x, const int32_t *d_y, const int32_t *d_count, int n_frames, int cap,
+                             const axt_grid *grid, int H, int W, int max_dist, int conn8, int max_gap,
+                             const int32_t *h_dmax, const int64_t *d_cost_units, int64_t thr_units,
+                             int t_begin, int t_end, int32_t *d_pred, int32_t *d_work, void *stream);
 int axt_chain_tracks(const int32_t *d_count, int n_frames, int cap, const int32_t *d_pred, int32_t *d_work,
                      int32_t *d_track, int32_t *d_n_tracks, void *stream);
 

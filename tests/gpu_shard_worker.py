@@ -22,7 +22,7 @@ def run(rank, world, port, q, total_frames, seed):
     tl = axtrack_amd.Timelapse(frames, name='shard')
     tl_masked = axtrack_amd.Timelapse(frames, name='shard', mask=synth.corridor_mask(512, 512, width=40, pitch=128))
     out = {}
-    for mode in ('hungarian', 'mcf', 'mcf+appearance', 'mcf+mask'):
+    for mode in ('hungarian', 'mcf', 'mcf+appearance', 'mcf+mask', 'hungarian+mask'):
         P = params.load_parameters()
         P['ASSOCIATION'] = mode.split('+')[0]
         if mode.endswith('appearance'):

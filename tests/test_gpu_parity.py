@@ -374,6 +374,49 @@ def test_inference_hungarian_mode_end_to_end(weights):
         assert list(tabs[f].anchor_x) == [r[2] for r in rows]
 
 
+def test_inference_hungarian_mode_on_a_masked_grid(weights):
+    """The frame-to-frame variant with path lengths from the masked-grid searches (axt_hungarian_pairs_grid): the
+    oracle's trajectories, which differ from those on the all-ones mask."""
+    import axtrack_amd
+    frames = synth.synth_frames(9, 512, 512, seed=27)
+    mask = synth.corridor_mask(512, 512, width=40, pitch=128)
+    P = dict(params.load_parameters(), ASSOCIATION='hungarian')
+    model = axtrack_amd.Detector(weights, max_batch=8)
+    ad = axtrack_amd.inference(axtrack_amd.Timelapse(frames, name='synth', mask=mask), model, None, P, None, None, None)
+    ref = orc.inference(frames, weights, mask=mask, P=orc.DEFAULTS, yolo=list(ad._yolo.cpu().numpy()), assoc='hungarian')
+    got = tracks_from_next(np.zeros(len(ad._track_flat)), ad._track_flat, ad._offs)
+    assert got == ref['trajs'] and ad.n_ids == len(ref['trajs'])
+    # scattered detections on a mask with walls, gaps and an island: the masked lengths change the association
+    from axtrack_amd.detections import transition_cost_table
+    H, W = 300, 420
+    mask = synth.corridor_mask(H, W, width=24, pitch=80)
+    mask[100:140, :] = False
+    mask[110:130, 200:260] = True
+    rng = np.random.default_rng(3)
+    F, cap = 6, 32
+    ys, xs = np.nonzero(mask)
+    dets = []
+    for t in range(F):
+        k = rng.choice(len(ys), 24, replace=False)
+        px, py = xs[k].copy(), ys[k].copy()
+        px[:5] = rng.integers(0, W, 5); py[:5] = rng.integers(0, H, 5)
+        dets.append((np.sort(rng.uniform(0.6, 1.0, 24).astype(np.float32))[::-1], px.astype(np.int64), py.astype(np.int64)))
+    x = np.zeros((F, cap), np.int32); y = np.zeros((F, cap), np.int32)
+    for t, d in enumerate(dets):
+        x[t, :24] = d[1]; y[t, :24] = d[2]
+    cnt = np.full(F, 24, np.int32)
+    table, dmax = transition_cost_table(params.DEPLOYED)
+    units = np.where(np.isfinite(table), np.rint(table * 1e6), 0).astype(np.int64)
+    offs = np.arange(F + 1) * 24
+    res = {}
+    for name, grid, m in (('masked', hp.Grid(mask, False), mask), ('open', None, None)):
+        track, _ = hp.hungarian_assoc(dev(x), dev(y), dev(cnt), H, W, dmax, units, 700000, mask=grid)
+        flat = track.cpu().numpy()[:, :24].reshape(-1)
+        res[name] = tracks_from_next(np.zeros(len(flat)), flat, offs)
+        assert res[name] == orc.hungarian_assoc(dets, H, W, mask=m), name
+    assert res['masked'] != res['open']
+
+
 # ----------------------------------------------------------------------------------------- a-9 on a real mask
 def test_path_cost_masked_grid_matches_oracle():
     """Corridor mask (BASELINE config 5 style), sources/targets on and off the mask, one outside the grid."""
@@ -601,7 +644,7 @@ def test_two_rank_frame_sharding(weights):
         assert p.exitcode == 0
     frames = synth.synth_frames(total + 4, 512, 512, seed=seed)
     import axtrack_amd
-    for mode in ('hungarian', 'mcf', 'mcf+appearance', 'mcf+mask'):
+    for mode in ('hungarian', 'mcf', 'mcf+appearance', 'mcf+mask', 'hungarian+mask'):
         P = params.load_parameters()
         P['ASSOCIATION'] = mode.split('+')[0]
         if mode.endswith('appearance'):
