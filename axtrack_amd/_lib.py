@@ -42,7 +42,8 @@ SIGNATURES = {
                                c_void_p, c_void_p, ctypes.POINTER(c_int64), c_void_p]),
     'axt_build_arcs_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                     c_int, c_void_p, c_void_p, c_void_p, c_double, c_double, c_double, c_void_p, c_void_p,
-                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_int64), c_void_p]),
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_int64), c_void_p,
+                                    c_void_p]),
     'axt_build_arcs_from_lengths': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                             ctypes.POINTER(c_int64), c_void_p]),

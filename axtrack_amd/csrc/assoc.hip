@@ -407,12 +407,12 @@ int axt_build_arcs_rows(const int32_t *d_x, const int32_t *d_y, const int32_t *d
                         const int32_t *h_dmax, const float *d_hist, const double *d_hist_sum, double vis_weight,
                         double miss_rate, double edge_cost_thr, int64_t *d_row_ptr, int32_t *d_work, int32_t *d_col,
                         int16_t *d_len, uint8_t *d_gap, const int64_t *d_cost_units, int64_t *d_cost, int64_t *n_arcs,
-                        void *stream)
+                        const int16_t *d_len_table, void *stream)
 {
-    AXT_REQUIRE(d_src_count, "axt_build_arcs_rows: null source counts");
     if (!d_hist)
-        return build_arcs_impl(d_x, d_y, d_count, n_frames, cap, grid, H, W, max_dist, conn8, max_gap, h_dmax, d_row_ptr, d_work,
-                               d_col, d_len, d_gap, d_cost_units, d_cost, n_arcs, nullptr, nullptr, stream, d_src_count);
+        return build_arcs_impl(d_x, d_y, d_count, n_frames, cap, d_len_table ? nullptr : grid, H, W, max_dist, conn8, max_gap,
+                               h_dmax, d_row_ptr, d_work, d_col, d_len, d_gap, d_cost_units, d_cost, n_arcs, nullptr, d_len_table,
+                               stream, d_src_count);
     AXT_REQUIRE(d_hist_sum, "axt_build_arcs_rows: null histogram sums");
     AXT_REQUIRE(vis_weight > 0.0 && vis_weight <= 1.0, "axt_build_arcs_rows: weight %g outside (0,1]", vis_weight);
     VisParams vp;
@@ -421,8 +421,8 @@ int axt_build_arcs_rows(const int32_t *d_x, const int32_t *d_y, const int32_t *d
     vp.w = vis_weight;
     vp.thr = edge_cost_thr;
     for (int g = 0; g < 8; ++g) vp.mp[g] = pow(miss_rate, (double)g);
-    return build_arcs_impl(d_x, d_y, d_count, n_frames, cap, grid, H, W, max_dist, conn8, max_gap, h_dmax, d_row_ptr, d_work,
-                           d_col, d_len, d_gap, nullptr, d_cost, n_arcs, &vp, nullptr, stream, d_src_count);
+    return build_arcs_impl(d_x, d_y, d_count, n_frames, cap, d_len_table ? nullptr : grid, H, W, max_dist, conn8, max_gap, h_dmax,
+                           d_row_ptr, d_work, d_col, d_len, d_gap, nullptr, d_cost, n_arcs, &vp, d_len_table, stream, d_src_count);
 }
 
 }  // extern "C"

@@ -376,15 +376,14 @@ class AxonDetections(object):
         """The reference's path dictionary (_compute_detections_astar_paths, AxonDetections.py:526-585): per frame pair
         a list over the detections of t_bef of lists over the detections of t of scipy coo matrices [H, W] (bool)
         marking the cells of a shortest path, or None beyond max_px_assoc_dist. On an all-ones mask every monotone
-        staircase between the two anchors is a shortest path; this one walks the columns first, then the rows (which
+        staircase between the two anchors is a shortest path; this one walks the columns first, then the rows
+        (8-connected: the diagonal first, then straight) (which
         of the equally short paths pyastar2d returns is unpinned; lengths are what the tracker
         uses). On a masked grid the GPU search walks back from every target along its distance field
         (axt_path_cells)."""
         from scipy import sparse
         if self.dataset.mask2d is not None:
             return self._masked_dets_paths()
-        if self.conn8:
-            raise NotImplementedError('staircase materialisation is implemented for the 4-connected grid')
         dists = self.astar_dists()
         cnt, _, x, y = self._host_dets()
         H, W = self.dataset.sizey, self.dataset.sizex
@@ -399,10 +398,19 @@ class AxonDetections(object):
                         row.append(None)
                         continue
                     xa, ya, xb, yb = int(x[t_bef, i]), int(y[t_bef, i]), int(x[t, j]), int(y[t, j])
-                    xs = np.arange(xa, xb + (1 if xb >= xa else -1), 1 if xb >= xa else -1)
-                    ys = np.arange(ya, yb + (1 if yb >= ya else -1), 1 if yb >= ya else -1)
-                    r = np.concatenate([np.full(len(xs), ya), ys[1:]])
-                    c = np.concatenate([xs, np.full(len(ys) - 1, xb)])
+                    sx, sy = (1 if xb >= xa else -1), (1 if yb >= ya else -1)
+                    if self.conn8:                      # diagonal first, then straight: max(|dx|,|dy|) + 1 cells
+                        k = min(abs(xb - xa), abs(yb - ya))
+                        dx, dy = abs(xb - xa) - k, abs(yb - ya) - k
+                        c = np.concatenate([xa + sx * np.arange(k + 1), xa + sx * (k + np.arange(1, dx + 1)),
+                                            np.full(dy, xb)]).astype(np.int64)
+                        r = np.concatenate([ya + sy * np.arange(k + 1), np.full(dx, ya + sy * k),
+                                            ya + sy * (k + np.arange(1, dy + 1))]).astype(np.int64)
+                    else:
+                        xs = np.arange(xa, xb + sx, sx)
+                        ys = np.arange(ya, yb + sy, sy)
+                        r = np.concatenate([np.full(len(xs), ya), ys[1:]])
+                        c = np.concatenate([xs, np.full(len(ys) - 1, xb)])
                     row.append(sparse.coo_matrix((np.ones(len(r)), (r, c)), (H, W), bool))
                 rows.append(row)
             out[lbl] = rows
@@ -523,10 +531,8 @@ class AxonDetections(object):
             hist, hsum = self._appearance()
             vis = dict(hist=hist, hsum=hsum, weight=vis_w, miss_rate=P['MCF_MISS_RATE'], thr=P['MCF_EDGE_COST_THR'])
         len_table = getattr(self, '_len_table', None)
-        if len_table is not None and vis is not None:
-            raise NotImplementedError('cached path lengths together with MCF_VIS_SIM_WEIGHT > 0')
         src_count = None
-        if shard is not None and len_table is None:
+        if shard is not None:
             # frame-sharded: this rank builds the arc rows of its own frames, one all-gather joins them (the path
             # searches of a masked grid are the expensive part of the association and shard with the frames)
             src_count = torch.zeros_like(self.d_count)

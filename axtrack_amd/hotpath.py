@@ -271,7 +271,7 @@ def build_arcs(x, y, count, H, W, dmax, cost_units=None, mask=None, max_dist=MAX
     row_ptr = torch.empty((n_frames * cap + 1,), dtype=torch.int64, device=dev)
     n_work = n_frames * cap * max_gap + n_frames + 1 + max_gap + 4
     if length_table is not None:
-        assert vis is None and tuple(length_table.shape) == (n_frames, cap, max_gap, cap) and length_table.dtype == torch.int16
+        assert tuple(length_table.shape) == (n_frames, cap, max_gap, cap) and length_table.dtype == torch.int16
         mask = None
     if mask is not None:
         if not isinstance(mask, Grid):
@@ -287,16 +287,15 @@ def build_arcs(x, y, count, H, W, dmax, cost_units=None, mask=None, max_dist=MAX
     head += (row_ptr.data_ptr(), work.data_ptr())
 
     def call(col, length, gap, cu, cost, what):
-        if src_count is not None:
-            assert length_table is None
+        if src_count is not None or (length_table is not None and vis is not None):
             v = vis or {}
-            rc = lib.axt_build_arcs_rows(x.data_ptr(), y.data_ptr(), count.data_ptr(), src_count.data_ptr(), n_frames, cap,
+            rc = lib.axt_build_arcs_rows(x.data_ptr(), y.data_ptr(), count.data_ptr(), _lib.dptr(src_count), n_frames, cap,
                                          mask._h if mask is not None else None, H, W, int(max_dist), int(bool(conn8)), max_gap,
                                          h_dmax.ctypes.data, v['hist'].data_ptr() if vis else None,
                                          v['hsum'].data_ptr() if vis else None, float(v.get('weight', 0.0)),
                                          float(v.get('miss_rate', 0.0)), float(v.get('thr', 0.0)), row_ptr.data_ptr(),
                                          work.data_ptr(), _lib.dptr(col), _lib.dptr(length), _lib.dptr(gap), _lib.dptr(cu),
-                                         _lib.dptr(cost), ctypes.byref(n_arcs), _stream())
+                                         _lib.dptr(cost), ctypes.byref(n_arcs), _lib.dptr(length_table), _stream())
         elif length_table is not None:
             rc = lib.axt_build_arcs_from_lengths(length_table.data_ptr(), x.data_ptr(), y.data_ptr(), count.data_ptr(), n_frames,
                                                  cap, int(max_dist), max_gap, h_dmax.ctypes.data, row_ptr.data_ptr(),

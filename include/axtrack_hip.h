@@ -228,14 +228,19 @@ int axt_build_arcs_vis(const int32_t *d_x, const int32_t *d_y, const int32_t *d_
  * its own frames' counts and zeros elsewhere -- while targets, detection numbering and integer costs are those of the
  * whole timelapse (d_count), so that the ranks' arc lists, concatenated in rank order, are exactly the single-process
  * list. d_hist == NULL: costs from d_cost_units as in axt_build_arcs; otherwise the appearance term as in
- * axt_build_arcs_vis (d_cost_units ignored). row_ptr covers all detections; rows outside the source frames are empty. */
+ * axt_build_arcs_vis (d_cost_units ignored). row_ptr covers all detections; rows outside the source frames are empty.
+ * This is the general entry point: d_src_count == NULL builds every row; d_len_table != NULL (i16
+ * [n_frames, cap, max_gap, cap], as for axt_build_arcs_from_lengths) takes the path lengths from a cache instead of
+ * computing them (grid ignored) -- the combination the reference's parameter search runs with the appearance term
+ * (assign_ids(astar_paths_cache='from') with MCF_VIS_SIM_WEIGHT > 0, AxonDetections.py:882,911-912). */
 int axt_build_arcs_rows(const int32_t *d_x, const int32_t *d_y, const int32_t *d_count, const int32_t *d_src_count,
                         int n_frames, int cap, const axt_grid *grid, int H, int W, int max_dist, int conn8,
                         int max_gap, const int32_t *h_dmax,
                         const float *d_hist, const double *d_hist_sum, double vis_weight, double miss_rate,
                         double edge_cost_thr,
                         int64_t *d_row_ptr, int32_t *d_work, int32_t *d_col, int16_t *d_len, uint8_t *d_gap,
-                        const int64_t *d_cost_units, int64_t *d_cost, int64_t *n_arcs, void *stream);
+                        const int64_t *d_cost_units, int64_t *d_cost, int64_t *n_arcs,
+                        const int16_t *d_len_table, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Global data association. Replaces libmot's MinCostFlowTracker as driven by

@@ -620,6 +620,44 @@ def test_masked_path_lengths_on_a_mask_with_many_components():
     assert got == want and len(want) > 50
 
 
+@pytest.mark.parametrize('variant', ['appearance', 'conn8'])
+def test_path_cache_with_the_appearance_term_and_on_the_8_connected_grid(weights, tmp_path, variant):
+    """Two more uses of the reference's path cache: read back while MCF_VIS_SIM_WEIGHT > 0 (what its parameter
+    search does, AxonDetections.py:882,911-912: lengths from the file, histograms from the pixels), and written on the
+    8-connected grid (diagonal-first staircases of max(|dx|,|dy|)+1 cells) -- each reproduces the direct result."""
+    import pickle
+    import axtrack_amd
+    frames = synth.synth_frames(9, 512, 512, seed=29) * np.float32(0.5)
+    P = params.load_parameters()
+    if variant == 'appearance':
+        P['MCF_VIS_SIM_WEIGHT'] = 0.2
+    else:
+        P['ASTAR_8_CONNECTED'] = True
+    model = axtrack_amd.Detector(weights, max_batch=8)
+    tl = axtrack_amd.Timelapse(frames, name='c2')
+    ad = axtrack_amd.AxonDetections(model, tl, P, str(tmp_path))
+    ad.detect_dataset()
+    ad.assign_ids(astar_paths_cache='to')
+    ref_tracks, ref_cost = ad._track_flat.copy(), ad.mcf_total_cost
+    paths = pickle.load(open(tmp_path / 'c2_astar_dets_paths.pkl', 'rb'))
+    dists = ad.astar_dists()
+    n = 0
+    for lbl, rows in paths.items():
+        for i, row in enumerate(rows):
+            for j, p in enumerate(row):
+                if p is None:
+                    continue
+                assert p.getnnz() == dists[lbl][i, j]
+                dr, dc = np.abs(np.diff(p.row)), np.abs(np.diff(p.col))
+                assert np.all(np.maximum(dr, dc) == 1) if variant == 'conn8' else np.all(dr + dc == 1)
+                n += 1
+    assert n > 100
+    ad2 = axtrack_amd.AxonDetections(model, tl, P, str(tmp_path))
+    ad2.detect_dataset()
+    ad2.assign_ids(astar_paths_cache='from')
+    assert np.array_equal(ad2._track_flat, ref_tracks) and ad2.mcf_total_cost == ref_cost
+
+
 # ----------------------------------------------------------------------------------------- multi-GPU path
 def test_two_rank_frame_sharding(weights):
     """Two ranks (gloo, both on cuda:0) each detect half of the frames, all-gather the detections, build the arcs /
