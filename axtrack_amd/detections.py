@@ -610,10 +610,12 @@ class AxonDetections(object):
             n_ids = int(ids[-1]) + 1 if len(ids) else 0
             id_row = torch.full((max(n_ids, 1),), -1, dtype=torch.int32, device=self.device)
             id_row[uniq.long()] = torch.arange(len(ids), dtype=torch.int32, device=self.device)
-        vals = hp.ided_table(track, self.d_conf, self.d_x, self.d_y, self.d_count, n_ids, self.reproduce_label_quirk,
-                             id_row, None if ids is None else len(ids))
-        return pd.DataFrame(vals, index=_axon_index(np.arange(n_ids) if ids is None else ids),
-                            columns=_ided_columns(len(self)), copy=False)
+        vals, wait = hp.ided_table(track, self.d_conf, self.d_x, self.d_y, self.d_count, n_ids, self.reproduce_label_quirk,
+                                   id_row, None if ids is None else len(ids))
+        df = pd.DataFrame(vals, index=_axon_index(np.arange(n_ids) if ids is None else ids),
+                          columns=_ided_columns(len(self)), copy=False)          # built while the copy is in flight
+        wait()
+        return df
 
     def _ided_block(self, track, a, b):
         """Frame-sharded runs: the dense table of a timelapse grows with frames x identities, so every rank
@@ -625,11 +627,13 @@ class AxonDetections(object):
         alive = torch.unique(tr[tr >= 0])
         id_row = torch.full((max(int(self.n_ids or 0), 1),), -1, dtype=torch.int32, device=self.device)
         id_row[alive.long()] = torch.arange(len(alive), dtype=torch.int32, device=self.device)
-        vals = hp.ided_table(tr, self.d_conf[a:b], self.d_x[a:b], self.d_y[a:b], self.d_count[a:b], int(self.n_ids or 0),
-                             False, id_row, len(alive))
+        vals, wait = hp.ided_table(tr, self.d_conf[a:b], self.d_x[a:b], self.d_y[a:b], self.d_count[a:b], int(self.n_ids or 0),
+                                   False, id_row, len(alive))
         cols = pd.MultiIndex.from_product([range(a, b), ['anchor_x', 'anchor_y', 'conf']], names=('frameID', 'detInfo'))
         self.IDed_dets_block = (a, b)
-        return pd.DataFrame(vals, index=_axon_index(alive.cpu().numpy()), columns=cols, copy=False)
+        df = pd.DataFrame(vals, index=_axon_index(alive.cpu().numpy()), columns=cols, copy=False)
+        wait()
+        return df
 
     def _track_dev(self):
         """Trajectory id of every detection slot on the device, i32 [F,cap] (-1: none)."""

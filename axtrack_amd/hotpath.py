@@ -362,7 +362,8 @@ def hungarian_assoc(x, y, count, H, W, dmax, cost_units, thr_units, max_dist=MAX
 
 def ided_table(track, conf, x, y, count, n_ids, label_quirk=True, id_row=None, n_rows=None):
     """IDed_dets_all's values (AxonDetections.py:825-842) as a pinned host f64 array [n_rows, 3*F]: filled on the
-    GPU (axt_ided_table), copied across once. id_row: optional i32 device tensor id -> row for ids with gaps."""
+    GPU (axt_ided_table), copied across once. id_row: optional i32 device tensor id -> row for ids with gaps.
+    Returns (array, wait): the copy is asynchronous, wait() returns when the array holds the table."""
     n_frames, cap = x.shape
     dev = x.device
     n_rows = int(n_ids if n_rows is None else n_rows)
@@ -375,8 +376,8 @@ def ided_table(track, conf, x, y, count, n_ids, label_quirk=True, id_row=None, n
                                               int(bool(label_quirk)), work.data_ptr(), table.data_ptr(), _stream()),
                    'axt_ided_table')
     host = torch.empty(table.shape, dtype=torch.float64, pin_memory=True)
-    host.copy_(table)
-    return host.numpy()
+    host.copy_(table, non_blocking=True)             # the caller wraps the array while the copy is in flight ...
+    return host.numpy(), torch.cuda.current_stream(dev).synchronize       # ... and calls this before handing it on
 
 
 def detection_confusion(conf, x, y, count, gx, gy, gcount, thrs, min_dist=23, k_mask=-1):
