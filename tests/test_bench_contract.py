@@ -1,0 +1,35 @@
+"""The line bench.py prints (as committed from the final GPU run, profiles/r01_k_bench.json) carries every field of the
+measurement contract, and the rocprofv3 summary committed beside it agrees with it on the dominant kernel."""
+import csv
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    b = json.load(open(os.path.join(ROOT, 'profiles', 'r01_k_bench.json')))
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in b, k
+    assert b['unit'] == 'frames/s' and b['higher_is_better'] is True and b['scaling'] == 'weak' and b['n_gpus'] == 1
+    assert b['vs_baseline'] is None and b['dtype'] == 'f32' and b['data'] == 'synthetic'
+    assert 'workload' in b['config'] and 'model' not in b['config']
+    assert abs(b['value'] - 252 * 1e3 / b['ms_per_step']) / b['value'] < 1e-3          # frames of one pass / time of one pass
+    r = b['roofline']
+    assert r['bound'] in ('hbm', 'mfma') and r['unit'] in ('GB/s', 'TFLOP/s')
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and 0 < r['frac'] < 1
+    assert r['traffic'] is None or r['traffic'] > 0
+    c = b['cpu_baseline']
+    assert c['kind'] in ('reference', 'port') and c['cores'] >= 1 and c['value'] > 0 and c['unit'] == 'frames/s' and c['sample']
+
+
+def test_rocprof_summary_agrees_with_the_bench_line():
+    b = json.load(open(os.path.join(ROOT, 'profiles', 'r01_k_bench.json')))
+    rows = list(csv.DictReader(open(os.path.join(ROOT, 'profiles', 'r01_k_kernels.csv'))))
+    dom = max(rows, key=lambda r: float(r['total_us']))
+    assert '40->80' in dom['kernel'] and '40>80' in b['roofline']['kernel']
+    # HIP events inside bench.py vs rocprofv3's average for the same kernel (profiled runs clock a few % lower)
+    assert abs(float(dom['avg_us']) / 1e3 - b['roofline']['avg_launch_ms']) / b['roofline']['avg_launch_ms'] < 0.08
+    t = json.load(open(os.path.join(ROOT, 'profiles', 'r01_k_traffic.json')))
+    assert abs(t['hbm_bytes_per_launch'] - b['roofline']['traffic']) / t['hbm_bytes_per_launch'] < 0.01
