@@ -456,7 +456,9 @@ class AxonDetections(object):
         (same nesting order) and score each against the labelled identities; one row per combination -- the five
         parameters, then mot_metrics.MOTCHALLENGE_METRICS -- written to '{dir}/MCF_params_results.csv' and returned.
         Every solve is the GPU arc build + flow solve of assign_ids (the detections and their appearance
-        histograms stay on the device between combinations); the parameters are restored afterwards."""
+        histograms stay on the device between combinations); the parameters are restored afterwards. On a masked
+        grid the arc builder's searches cover path lengths up to 251 cells: thresholds that admit longer paths
+        (edge_cost_thr > 0.7 at the deployed miss rate) are refused with an error rather than answered approximately."""
         from . import mot_metrics
         if not self.labelled:
             raise ValueError("no labels: call set_groundtruth() first")
