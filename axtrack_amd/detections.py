@@ -274,11 +274,11 @@ class AxonDetections(object):
         return prc_rcl_f1
 
     # ------------------------------------------------------------------ association (AxonDetections.py:505-524)
-    def assign_ids(self, astar_paths_cache=None, assigedIDs_cache=None):
+    def assign_ids(self, astar_paths_cache=None, assigedIDs_cache=None, _len_table=None):
         """AxonDetections.py:505-524. astar_paths_cache: 'from' adopts the path lengths of a
         '{name}_astar_dets_paths.pkl' (the reference's format: per frame pair a nested list of coo matrices / None)
         instead of computing them; 'to' writes such a file (astar_dets_paths)."""
-        self._len_table = None
+        self._len_table = _len_table
         if assigedIDs_cache != 'from':
             if astar_paths_cache == 'from':
                 self._len_table = self._length_table_from_paths(self.from_cache('astar_dets_paths'))
@@ -354,6 +354,20 @@ class AxonDetections(object):
                                  self.dataset.sizey, self.dataset.sizex, mask, self.max_px_assoc_dist, self.conn8)
                 out[lbl] = D.cpu().numpy()
         return out
+
+    def _length_table_from_dists(self, dists):
+        """astar_dists() (int matrices per frame pair, max_px_assoc_dist = none) as the i16 table [F, cap, gaps, cap]
+        the arc builder reads (0 = none)."""
+        F, cap, gaps = len(self), self.d_x.shape[1], self.P['MCF_MAX_NUM_MISSES'] + 1
+        table = np.zeros((F, cap, gaps, cap), np.int16)
+        for t in range(F):
+            for t_bef in range(t - 1, t - (gaps + 1), -1):
+                if t_bef < 0:
+                    continue
+                D = dists[f'{self.dataset.name}_t:{t:0>3}-t:{t_bef:0>3}']
+                if D.ndim == 2 and D.size:
+                    table[t_bef, :D.shape[0], t - t_bef - 1, :D.shape[1]] = np.where(D >= self.max_px_assoc_dist, 0, D)
+        return torch.from_numpy(table).to(self.device)
 
     def _length_table_from_paths(self, paths):
         """_get_astar_path_distances (AxonDetections.py:717-752) of a cached path dictionary, as the i16 table
@@ -457,8 +471,8 @@ class AxonDetections(object):
         parameters, then mot_metrics.MOTCHALLENGE_METRICS -- written to '{dir}/MCF_params_results.csv' and returned.
         Every solve is the GPU arc build + flow solve of assign_ids (the detections and their appearance
         histograms stay on the device between combinations); the parameters are restored afterwards. On a masked
-        grid the arc builder's searches cover path lengths up to 251 cells: thresholds that admit longer paths
-        (edge_cost_thr > 0.7 at the deployed miss rate) are refused with an error rather than answered approximately."""
+        grid the path lengths are computed once, exactly and up to max_px_assoc_dist (astar_dists), and reused by every
+        combination -- as the reference reuses its path cache."""
         from . import mot_metrics
         if not self.labelled:
             raise ValueError("no labels: call set_groundtruth() first")
@@ -467,6 +481,9 @@ class AxonDetections(object):
         keys = ('MCF_EDGE_COST_THR', 'MCF_ENTRY_EXIT_COST', 'MCF_MISS_RATE', 'MCF_VIS_SIM_WEIGHT', 'MCF_CONF_CAPPING_METHOD')
         before = {k: self.P[k] for k in keys}
         results = []
+        # masked grid: the exact path lengths once, for every threshold of the grid (the reference reads its path cache
+        # in every iteration, :882); all-ones masks have closed-form lengths
+        lengths = self._length_table_from_dists(self.astar_dists()) if self.dataset.mask2d is not None else None
         try:
             for ec in edge_cost_thr_values:
                 for eec in entry_exit_cost_values:
@@ -474,7 +491,7 @@ class AxonDetections(object):
                         for vsw in vis_sim_weight_values:
                             for ccm in conf_capping_method_values:
                                 self.P.update(dict(zip(keys, (ec, eec, mr, vsw, ccm))))
-                                self.assign_ids()
+                                self.assign_ids(_len_table=lengths)
                                 pred = self.get_frame_dets('IDed', None, libmot=True) if self._solved else None
                                 ev = mot_metrics.compare_to_groundtruth(target, pred, float(self.nms_min_dist) ** 2)
                                 results.append(pd.concat([pd.Series((ec, eec, mr, vsw, ccm), names, dtype=object),

@@ -1073,3 +1073,46 @@ def test_mcf_parameter_search_rows_match_the_oracle(golden, tmp_path):
         assert perfect or not is_label_combo
         n_perfect += perfect
     assert 1 <= n_perfect < 8                       # the grid does change the association
+
+
+def test_mcf_parameter_search_on_a_masked_grid_with_wide_thresholds(tmp_path):
+    """On a masked grid the search computes the exact path lengths once (up to 500 cells) and reuses them for every
+    combination, so thresholds that admit paths beyond the 251-cell window of the hot-path searches are served too:
+    every row's association equals the oracle's under those parameters."""
+    import axtrack_amd, pandas as pd
+    from axtrack_amd import mot_metrics
+    from axtrack_amd.detections import AxonDetections
+    H, W = 300, 420
+    mask = synth.corridor_mask(H, W, width=24, pitch=80)
+    mask[100:140, :] = False
+    rng = np.random.default_rng(8)
+    ys, xs = np.nonzero(mask)
+    F = 5
+    dets = []
+    for t in range(F):
+        k = rng.choice(len(ys), 20, replace=False)
+        px, py = xs[k].copy(), ys[k].copy()
+        px[:3] = rng.integers(0, W, 3); py[:3] = rng.integers(0, H, 3)
+        dets.append((np.sort(rng.uniform(0.6, 1.0, 20).astype(np.float32))[::-1], px.astype(np.int64), py.astype(np.int64)))
+    tl = axtrack_amd.Timelapse(np.zeros((F + 4, H, W), np.float32), name='synth', mask=mask)
+    P = dict(params.load_parameters(), MCF_MIN_FLOW=1)
+    ad = AxonDetections(None, tl, P, str(tmp_path))
+    ad._set_detections_from_tables([pd.DataFrame({'conf': c, 'anchor_x': x, 'anchor_y': y}) for c, x, y in dets])
+    ad.assign_ids()
+    frame, tid, _, x, y = ad.ided_arrays()
+    ad.set_groundtruth([(x[frame == t], y[frame == t], tid[frame == t]) for t in range(F)])
+    res = ad.search_MCF_params(edge_cost_thr_values=[0.7, 1.2, 3], entry_exit_cost_values=[2], miss_rate_values=[0.6],
+                               vis_sim_weight_values=[0], conf_capping_method_values=['scale_to_max'])
+    target = ad.get_frame_dets('groundtruth', None, libmot=True)
+    D = orc.all_path_matrices(dets, H, W, mask)
+    n_arcs = []
+    for _, row in res.iterrows():
+        Po = dict(orc.DEFAULTS, MCF_MIN_FLOW=1, MCF_EDGE_COST_THR=row.edge_cost_thr)
+        trajs, _ = orc.mcf_solve(dets, D, Po)
+        rows = [[f, i, dets[f][1][k] - 35, dets[f][2][k] - 35] for i, tr in enumerate(trajs or []) for f, k in tr]
+        pred = pd.DataFrame(rows, columns=['FrameId', 'Id', 'X', 'Y']).set_index(['FrameId', 'Id']) if rows else None
+        want = mot_metrics.summarize(mot_metrics.compare_to_groundtruth(target, pred, 23.0 ** 2))
+        got = row[mot_metrics.MOTCHALLENGE_METRICS].astype(float)
+        assert np.allclose(got.to_numpy(), want.to_numpy(), rtol=0, atol=1e-12, equal_nan=True), (row.edge_cost_thr, got, want)
+        n_arcs.append(len(orc.build_flow_graph(dets, D, Po)[0]))
+    assert res.iloc[0].mota == 1 and n_arcs[0] < n_arcs[1] <= n_arcs[2]          # the wider thresholds do admit more arcs
