@@ -550,6 +550,10 @@ class AxonDetections(object):
             hist, hsum = self._appearance()
             vis = dict(hist=hist, hsum=hsum, weight=vis_w, miss_rate=P['MCF_MISS_RATE'], thr=P['MCF_EDGE_COST_THR'])
         len_table = getattr(self, '_len_table', None)
+        if len_table is None and masked and max(dmax) - 1 > 250:
+            # the hot-path searches of the arc builder cover paths of up to 251 cells (the deployed threshold admits
+            # exactly that); wider thresholds take the exact, slower search over the whole range
+            len_table = self._length_table_from_dists(self.astar_dists())
         src_count = None
         if shard is not None:
             # frame-sharded: this rank builds the arc rows of its own frames, one all-gather joins them (the path

@@ -1116,3 +1116,8 @@ def test_mcf_parameter_search_on_a_masked_grid_with_wide_thresholds(tmp_path):
         assert np.allclose(got.to_numpy(), want.to_numpy(), rtol=0, atol=1e-12, equal_nan=True), (row.edge_cost_thr, got, want)
         n_arcs.append(len(orc.build_flow_graph(dets, D, Po)[0]))
     assert res.iloc[0].mota == 1 and n_arcs[0] < n_arcs[1] <= n_arcs[2]          # the wider thresholds do admit more arcs
+    # a plain assign_ids() with such a threshold falls back to the exact lengths by itself
+    ad.P['MCF_EDGE_COST_THR'] = 1.2
+    ad.assign_ids()
+    trajs, total = orc.mcf_solve(dets, D, dict(orc.DEFAULTS, MCF_MIN_FLOW=1, MCF_EDGE_COST_THR=1.2))
+    assert tracks_from_next(np.zeros(len(ad._track_flat)), ad._track_flat, ad._offs) == trajs and ad.mcf_total_cost == total
