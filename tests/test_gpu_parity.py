@@ -829,6 +829,22 @@ def test_inference_with_appearance_term(weights):
     assert ad0.mcf_total_cost != ad.mcf_total_cost
 
 
+def test_inference_with_appearance_term_on_a_masked_grid(weights):
+    """MCF_VIS_SIM_WEIGHT > 0 widens the candidate distances beyond the 251-cell window of the hot-path searches; on a
+    masked grid the arc builder then runs on the exact path lengths. Same trajectories as the oracle."""
+    import axtrack_amd
+    frames = synth.synth_frames(9, 512, 512, seed=33) * np.float32(0.5)
+    mask = synth.corridor_mask(512, 512, width=40, pitch=128)
+    frames = frames * mask[None].astype(np.float32)
+    P = dict(params.load_parameters(), MCF_VIS_SIM_WEIGHT=0.3, MCF_MIN_FLOW=1)
+    model = axtrack_amd.Detector(weights, max_batch=8)
+    ad = axtrack_amd.inference(axtrack_amd.Timelapse(frames, name='synth', mask=mask), model, None, P, None, None, None)
+    ref = orc.inference(frames, weights, mask=mask, P=dict(orc.DEFAULTS, MCF_VIS_SIM_WEIGHT=0.3, MCF_MIN_FLOW=1),
+                        yolo=list(ad._yolo.cpu().numpy()))
+    got = tracks_from_next(np.zeros(len(ad._track_flat)), ad._track_flat, ad._offs)
+    assert got == ref['trajs'] and abs(ad.mcf_total_cost - ref['total_cost']) <= 65536 * 4
+
+
 # ----------------------------------------------------------------------------------------- f-4 (next row)
 def test_detection_metrics_match_the_reference(golden):
     """compute_TP_FP_FN over all frames and the 13 thresholds in one launch, and the per-frame API, against what the
