@@ -122,7 +122,9 @@ class AxonDetections(object):
             dist.all_gather_into_tensor(g_hsum, hsum.contiguous(), group=group)
             self._hist = (g_hist, g_hsum)
         self.d_conf, self.d_x, self.d_y, self.d_count = all_gather_detections(
-            self.d_conf, self.d_x, self.d_y, self.d_count, group)
+            self.d_conf, self.d_x, self.d_y, self.d_count, group,
+            check_shapes=not getattr(self.dataset, '_gather_shapes_agree', False))
+        self.dataset._gather_shapes_agree = True          # the shapes follow from the timelapse: checked once
         self._host, self._det_tables = None, None
         if dist.is_initialized() and dist.get_world_size(group) > 1:
             r = dist.get_rank(group)
@@ -200,7 +202,8 @@ class AxonDetections(object):
         half = self.axon_box_size // 2
         frame_id = np.full(conf.shape, t)
         boxs = np.full(conf.shape, self.axon_box_size)
-        axon_id = np.array([int(idx[-3:]) for idx in detection.index])
+        # the reference takes idx[-3:], which folds identities >= 1000 onto 0..999; the whole number is used here
+        axon_id = np.array([_axon_number(idx) for idx in detection.index])
         det_libmot = np.stack([frame_id, axon_id, x - half, y - half, boxs, boxs, conf]).T
         cols = ['FrameId', 'Id', 'X', 'Y', 'Width', 'Height', 'conf']
         return pd.DataFrame(det_libmot, columns=cols).set_index(['FrameId', 'Id'])
@@ -330,7 +333,7 @@ class AxonDetections(object):
             tx, ty = t.anchor_x.to_numpy(dtype=np.int64), t.anchor_y.to_numpy(dtype=np.int64)
             for name, ax, ay in zip(t.index, tx, ty):
                 k = np.nonzero((x[f, :cnt[f]] == ax) & (y[f, :cnt[f]] == ay))[0][0]   # exact anchor match (:804-808)
-                track[offs[f] + k] = int(name[-3:])
+                track[offs[f] + k] = _axon_number(name)
         self._track_flat_cache, self._d_track = track, None
         self.n_ids = None                                           # unknown: ids are whatever the cache holds
         self._solved, self._ided_tables = True, list(tables)
@@ -696,6 +699,11 @@ def _ided_columns(F):
 
 
 _AXON_NAMES = [f'Axon_{i:0>3}' for i in range(2048)]
+
+
+def _axon_number(name):
+    """'Axon_012' -> 12, 'Axon_1234' -> 1234 (names are zero-padded to three digits, not truncated)."""
+    return int(str(name).split('_')[-1])
 
 
 def _axon_index(ids):

@@ -143,8 +143,9 @@ def preprocess_u16(raw, mask=None, offset=0.0, clip_lower=0.0, log_correct=True,
     return out
 
 
-def tile_occupancy(frames):
-    """Kept tiles, row-major list of (tile_row, tile_col) (Timelapse.py:551-558)."""
+def tile_occupancy_bytes(frames):
+    """Per-tile occupancy of this block of frames as a device u8 tensor [tile_rows * tile_cols] (1 = some pixel of
+    the tile is non-zero at some time point)."""
     T_all, H, W = frames.shape
     nty, ntx = -(-H // TILE), -(-W // TILE)
     occ = torch.empty(nty * ntx, dtype=torch.uint8, device=frames.device)
@@ -152,8 +153,19 @@ def tile_occupancy(frames):
     with torch.cuda.device(frames.device):
         _lib.check(lib.axt_tile_occupancy(frames.data_ptr(), T_all, H, W, occ.data_ptr(), _stream()),
                    'axt_tile_occupancy')
+    return occ
+
+
+def tile_list(occ, H, W):
+    """Occupancy bytes -> row-major list of kept (tile_row, tile_col)."""
+    nty, ntx = -(-H // TILE), -(-W // TILE)
     occ = occ.cpu().numpy().reshape(nty, ntx)
     return [tuple(int(v) for v in ix) for ix in np.argwhere(occ)]
+
+
+def tile_occupancy(frames):
+    """Kept tiles, row-major list of (tile_row, tile_col) (Timelapse.py:551-558)."""
+    return tile_list(tile_occupancy_bytes(frames), frames.shape[1], frames.shape[2])
 
 
 def decode_stitch_nms(yolo, tile_yx, conf_thr=CONF_FLOOR, min_dist=23, cap=None):
@@ -354,7 +366,8 @@ def hungarian_assoc(x, y, count, H, W, dmax, cost_units, thr_units, max_dist=MAX
                                                 work.data_ptr(), _stream()), 'axt_hungarian_pairs_grid')
         if frame_range is not None:
             import torch.distributed as dist
-            dist.all_reduce(pred, op=dist.ReduceOp.MAX, group=group)
+            from . import sharded
+            sharded._collective('hungarian_links_allreduce', lambda: dist.all_reduce(pred, op=dist.ReduceOp.MAX, group=group))
         _lib.check(lib.axt_chain_tracks(count.data_ptr(), n_frames, cap, pred.data_ptr(), work.data_ptr(),
                                         track.data_ptr(), n_tracks.data_ptr(), _stream()), 'axt_chain_tracks')
     return track, n_tracks

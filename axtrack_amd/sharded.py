@@ -7,8 +7,26 @@ rank all detections. The per-frame work of the association stays sharded -- the 
 (one MAX all-reduce joins the links), the flow tracker's arc rows with their path searches (all_gather_arcs) -- and
 only the deterministic integer-cost flow solve is replicated (a unique optimum: no broadcast needed).
 """
+import time
+
 import torch
 import torch.distributed as dist
+
+COLLECTIVE_MS = None        # bench.py: set to a dict to collect the wall time of every collective (synchronised; off by default)
+
+
+def _collective(name, fn):
+    """Run one collective; when COLLECTIVE_MS is a dict, bracket it with device synchronisations and record its wall time."""
+    if COLLECTIVE_MS is None:
+        return fn()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    t = time.perf_counter()
+    r = fn()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    COLLECTIVE_MS[name] = COLLECTIVE_MS.get(name, 0.0) + (time.perf_counter() - t) * 1e3
+    return r
 
 
 def frame_block(n_frames_total, rank, world):
@@ -19,16 +37,26 @@ def frame_block(n_frames_total, rank, world):
     return rank * per, per
 
 
-def all_gather_detections(conf, x, y, count, group=None):
+def all_gather_detections(conf, x, y, count, group=None, check_shapes=True):
     """conf f32 [F,cap], x/y i32 [F,cap], count i32 [F] per rank -> the same arrays for all
     world*F frames, rank-major. One collective on a packed i32 buffer [F, 3*cap+1]."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return conf, x, y, count
     world = dist.get_world_size(group)
     F, cap = conf.shape
+    # every rank must bring the same [F, cap]: cap follows from the kept-tile list, which is a property of the whole
+    # timelapse (Timelapse.sync_tile_occupancy), F from the equal frame blocks. A mismatch would hang or corrupt the
+    # gather, so it is checked first (one tiny collective, once per timelapse: AxonDetections.gather_detections).
+    shape = torch.tensor([F, cap, -F, -cap], dtype=torch.int64, device=conf.device)
+    if check_shapes:
+        _collective('shape_check_allreduce', lambda: dist.all_reduce(shape, op=dist.ReduceOp.MAX, group=group))
+    if check_shapes and (shape[0].item() != -shape[2].item() or shape[1].item() != -shape[3].item()):
+        raise ValueError(f'frame-sharded ranks disagree on the detection array shape (this rank: [{F}, {cap}]; '
+                         f'max [{shape[0].item()}, {shape[1].item()}]): call Timelapse.sync_tile_occupancy() on every '
+                         f'rank before detect_dataset() and give every rank the same number of frames')
     packed = torch.cat([conf.contiguous().view(torch.int32), x, y, count.view(F, 1)], dim=1).contiguous()
     out = torch.empty((world * F, 3 * cap + 1), dtype=torch.int32, device=packed.device)
-    dist.all_gather_into_tensor(out, packed, group=group)
+    _collective('detections_allgather', lambda: dist.all_gather_into_tensor(out, packed, group=group))
     g_conf = out[:, :cap].contiguous().view(torch.float32)
     g_x = out[:, cap:2 * cap].contiguous()
     g_y = out[:, 2 * cap:3 * cap].contiguous()
@@ -49,14 +77,14 @@ def all_gather_arcs(row_ptr, col, length, gap, cost, n_det, group=None):
     counts = torch.zeros((n_det + world,), dtype=torch.int64, device=dev)
     counts[:n_det] = row_ptr[1:n_det + 1] - row_ptr[:n_det]
     counts[n_det + rank] = n
-    dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+    _collective('arc_counts_allreduce', lambda: dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group))
     sizes = counts[n_det:].tolist()
     longest = max(max(sizes), 1)
     packed = torch.zeros((longest, 2), dtype=torch.int64, device=dev)
     packed[:n, 0] = cost
     packed[:n, 1] = col.to(torch.int64) | (length.to(torch.int64) << 32) | (gap.to(torch.int64) << 48)
     out = torch.empty((world * longest, 2), dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(out, packed, group=group)
+    _collective('arcs_allgather', lambda: dist.all_gather_into_tensor(out, packed, group=group))
     parts = [out[r * longest:r * longest + sizes[r]] for r in range(world)]
     allp = torch.cat(parts, dim=0)
     g_row_ptr = torch.zeros((n_det + 1,), dtype=torch.int64, device=dev)

@@ -50,6 +50,24 @@ class Timelapse:
             self._tile_yx = hp.tile_occupancy(self.frames)
         return self._tile_yx
 
+    def sync_tile_occupancy(self, group=None):
+        """Frame-sharded runs: this object holds one rank's block of frames, but the reference decides which tiles
+        are empty over the WHOLE timelapse (non_empty_tiles.any over all time points, Timelapse.py:551-558). One MAX
+        all-reduce of the occupancy bytes gives every rank the timelapse-wide tile list -- and with it the same
+        n_tiles, hence the same detection capacity, which the all-gather of the detections relies on."""
+        import torch.distributed as dist
+        from . import hotpath as hp
+        occ = hp.tile_occupancy_bytes(self.frames)
+        if dist.is_initialized() and dist.get_world_size(group) > 1:
+            if dist.get_backend(group) == 'gloo':
+                occ_h = occ.cpu()
+                dist.all_reduce(occ_h, op=dist.ReduceOp.MAX, group=group)
+                occ = occ_h
+            else:
+                dist.all_reduce(occ, op=dist.ReduceOp.MAX, group=group)
+        self._tile_yx = hp.tile_list(occ, self.sizey, self.sizex)
+        return self._tile_yx
+
     @property
     def device(self):
         return self.frames.device

@@ -50,6 +50,8 @@ def main():
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--cpu-frames', type=int, default=252, help='detection frames of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--no-profile', action='store_true', help='do not bracket kernels with HIP events')
+    ap.add_argument('--no-verify', action='store_true',
+                    help='skip the self-check of the benchmarked configuration against the CPU oracle (outside the timed region)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='gloo only for rehearsals')
     ap.add_argument('--single-device', action='store_true',
                     help='rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)')
@@ -81,6 +83,7 @@ def main():
     # this rank's block of the global timelapse, with its 2-frame halo on both sides
     f0 = rank * per_rank
     frames = synth.synth_frames(T_all_global, H, W, seed=0, t_range=(f0, f0 + per_rank + 4))
+    frames_host = frames if (rank == 0 and not args.no_verify) else None     # the checker's copy (rank 0's block)
     sd = synth.synth_state_dict(42)
     P = params.load_parameters()
     P['DEVICE'] = str(dev)
@@ -89,6 +92,8 @@ def main():
     model = axtrack_amd.Detector(sd, max_batch=min(per_rank * n_tiles, 1024), device=dev)
     tl = axtrack_amd.Timelapse(frames, name='bench', device=dev)
     del frames
+    if world > 1:
+        tl.sync_tile_occupancy()          # the kept-tile list is a property of the whole timelapse (Timelapse.py:551-558)
 
     def step():
         ad = axtrack_amd.AxonDetections(model, tl, P, None)
@@ -144,12 +149,28 @@ def main():
         torch.cuda.synchronize(dev)
         stages[name] = round((time.perf_counter() - t) * 1e3, 3)
         return r
+    from axtrack_amd import sharded
     ad2 = axtrack_amd.AxonDetections(model, tl, P, None)
     timed('detect_ms', lambda: ad2.detect_dataset(cache=None))
     if args.workload == 'c3':
+        sharded.COLLECTIVE_MS = {}                     # per-collective wall time of this (untimed, synchronised) step
         if world > 1:
             timed('allgather_ms', ad2.gather_detections)
         timed('associate_ms', lambda: ad2.assign_ids(None, None))
+        collectives = {k: round(v, 3) for k, v in sharded.COLLECTIVE_MS.items()}
+        sharded.COLLECTIVE_MS = None
+
+    # every rank must hold the same association: compare a hash of the trajectory ids of the whole timelapse
+    same_on_all_ranks = None
+    if args.workload == 'c3' and world > 1:
+        import hashlib
+        digest = hashlib.sha256(np.ascontiguousarray(ad._track_flat).tobytes()).digest()[:8]
+        h = torch.tensor([int.from_bytes(digest, 'little', signed=True)], dtype=torch.int64, device=dev)
+        lo, hi = h.clone(), h.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        same_on_all_ranks = bool(lo.item() == hi.item())
+        assert same_on_all_ranks, 'ranks disagree on the trajectories of the gathered timelapse'
 
     # the other association variant, measured in the same run (untimed region, one step) for transparency
     other = None
@@ -182,6 +203,14 @@ def main():
             'stages': stages,
             'detections': int(ad._host_dets()[0].sum()),
         }
+        if world > 1:
+            out['rccl_world'] = dist.get_world_size() if args.backend == 'nccl' else 0
+            out['backend'] = args.backend
+            if args.workload == 'c3':
+                out['collectives_ms'] = collectives
+                out['tracks_identical_on_all_ranks'] = same_on_all_ranks
+        if not args.no_verify:
+            out.update(verify(args, ad, frames_host, sd, per_rank, world))
         if args.workload == 'c3':
             out['n_ids'] = getattr(ad, 'n_ids', None)
             if other:
@@ -212,6 +241,53 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def verify(args, ad, frames_host, sd, per_rank, world):
+    """Self-check of the configuration that was just timed (same Detector, same launch shapes), outside the timed region,
+    against the CPU oracle: YOLO grids of 8 frames sampled across every front-layer launch within 2e-4 of the oracle's
+    f32 forward pass; the detection lists of ALL of rank 0's frames bit-exact given those grids; the trajectories equal
+    to the oracle's association (one GPU; with several ranks the association is checked through the cross-rank hash).
+    The flow tracker's oracle is a Bellman-Ford solver (~40 s at config 3's size)."""
+    from oracle import oracle as orc
+    t0 = time.perf_counter()
+    yolo = ad._yolo.cpu().numpy()                          # this rank's frames [per_rank, n_tiles, 12, 12, 3]
+    F, n_tiles = yolo.shape[:2]
+    per_launch = max(128 // n_tiles, 1)
+    sample = sorted({0, per_launch - 1, per_launch % F, (per_launch + 1) % F, F // 3, F // 2, (2 * F) // 3, F - 1})
+    err = 0.0
+    for t in sample:
+        ref = orc.cnn_forward(sd, orc.frame_tile_stack(frames_host, t, ad.tile_yx))
+        err = max(err, float(np.abs(yolo[t] - ref).max() / (1.0 + np.abs(ref).max())))
+    ok_cnn = err < 2e-4
+    ref_dets = orc.detect_from_yolo(list(yolo), ad.tile_yx)
+    cnt, conf, x, y = ad._host_dets()
+    ok_det = True
+    for t, (rc, rx, ry) in enumerate(ref_dets):            # after a gather the arrays hold all ranks' frames; rank 0's come first
+        n = len(rc)
+        ok_det &= bool(cnt[t] == n and np.array_equal(conf[t, :n], rc) and np.array_equal(x[t, :n], rx)
+                       and np.array_equal(y[t, :n], ry))
+    ok_assoc, what = None, 'not checked'
+    if args.workload == 'c3' and world == 1:
+        Pc = dict(orc.DEFAULTS)
+        ref = orc.inference(frames_host, sd, P=Pc, yolo=list(yolo), assoc=args.assoc)
+        frame_of = np.repeat(np.arange(len(cnt)), cnt)
+        offs = np.concatenate([[0], np.cumsum(cnt)])
+        got = {}
+        for k, tid in enumerate(ad._track_flat):
+            if tid >= 0:
+                got.setdefault(int(tid), []).append((int(frame_of[k]), int(k - offs[frame_of[k]])))
+        ok_assoc = [sorted(got[i]) for i in sorted(got)] == ref['trajs']
+        if args.assoc == 'mcf':
+            ok_assoc &= bool(ad.mcf_total_cost == ref['total_cost'])
+        what = f'trajectories equal to the oracle ({args.assoc})'
+    elif args.workload == 'c3':
+        what = 'cross-rank hash of the trajectories (tracks_identical_on_all_ranks)'
+    return {'verified': bool(ok_cnn and ok_det and ok_assoc is not False),
+            'verify': {'cnn_frames': sample, 'cnn_max_rel_err': float(f'{err:.3e}'), 'cnn_ok': ok_cnn,
+                       'detections_bit_exact_frames': len(ref_dets), 'detections_ok': ok_det,
+                       'association': what, 'association_ok': ok_assoc,
+                       'seconds': round(time.perf_counter() - t0, 1)}}
 
 
 def committed_traffic(kernel_name):

@@ -19,7 +19,9 @@ def pytest_sessionstart(session):
     so that a fresh checkout can run the suite. hipcc cross-compiles for gfx950 without a GPU."""
     import subprocess
     for d in (os.path.join(ROOT, 'axtrack_amd', 'csrc'), os.path.join(ROOT, 'oracle')):
-        subprocess.run(['make', '-C', d, '-s', '-j8'], check=False, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        r = subprocess.run(['make', '-C', d, '-s', '-j8'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:               # never run the suite against a stale library
+            pytest.exit(f'building {d} failed:\n{r.stdout[-4000:]}', returncode=2)
 
 
 @pytest.fixture(scope='session')

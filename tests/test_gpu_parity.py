@@ -699,6 +699,39 @@ def test_two_rank_frame_sharding(weights):
             assert cols == 3 * (total // 2) and rows <= ad.n_ids
 
 
+def test_two_rank_sharding_with_a_tile_that_is_empty_on_one_rank(weights):
+    """The reference drops a tile only if it is empty at EVERY time point (Timelapse.py:551-558). Frame-sharded, the
+    right tile is empty in all of rank 0's frames: its own scan would keep one tile (capacity 144), rank 1's two (288).
+    The gather refuses mismatched shapes; after Timelapse.sync_tile_occupancy() both ranks use the timelapse-wide
+    list and reproduce the single-process result."""
+    import socket
+    import torch.multiprocessing as mp
+    import gpu_shard_worker
+    import axtrack_amd
+    total, seed = 12, 77
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=gpu_shard_worker.run_tiles, args=(r, 2, port, q, total, seed)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0]['local'] == [(0, 0)] and res[1]['local'] == [(0, 0), (0, 1)]
+    assert res[0]['refused'] and res[1]['refused']
+    frames = gpu_shard_worker.tiles_frames(total, seed)
+    P = dict(params.load_parameters(), ASSOCIATION='hungarian')
+    ad = _run_inference(frames, weights, P, name='tiles')
+    for r in (0, 1):
+        assert res[r]['tiles'] == ad.tile_yx == [(0, 0), (0, 1)] and res[r]['cap'] == 288
+        assert res[r]['n_ids'] == ad.n_ids and res[r]['track'] == ad._track_flat.tobytes()
+        assert res[r]['table'] == ad.IDed_dets_all.to_numpy().tobytes()
+
+
 # ----------------------------------------------------------------------------------------- f-2 (next row)
 def test_path_cache_round_trip_in_the_references_format(weights, tmp_path):
     """'{name}_astar_dets_paths.pkl': written ('to') in the reference's format -- nested lists of scipy coo matrices /
@@ -1137,3 +1170,74 @@ def test_mcf_parameter_search_on_a_masked_grid_with_wide_thresholds(tmp_path):
     ad.assign_ids()
     trajs, total = orc.mcf_solve(dets, D, dict(orc.DEFAULTS, MCF_MIN_FLOW=1, MCF_EDGE_COST_THR=1.2))
     assert tracks_from_next(np.zeros(len(ad._track_flat)), ad._track_flat, ad._offs) == trajs and ad.mcf_total_cost == total
+
+
+# ----------------------------------------------------------------------------------------- the benchmarked launch shapes
+def _assert_dets_equal_oracle(ad, ref_dets):
+    cnt, conf, x, y = ad._host_dets()
+    assert len(cnt) == len(ref_dets)
+    for t, (rc, rx, ry) in enumerate(ref_dets):
+        n = len(rc)
+        assert cnt[t] == n, f'frame {t}: {cnt[t]} detections, oracle {n}'
+        assert np.array_equal(conf[t, :n].view(np.uint32), np.asarray(rc, np.float32).view(np.uint32)), f'frame {t}'
+        assert np.array_equal(x[t, :n], rx) and np.array_equal(y[t, :n], ry), f'frame {t}'
+
+
+@pytest.mark.parametrize('max_batch,T_all,size,name', [(252, 256, 512, 'c3'), (512, 132, 1024, 'c4share')])
+def test_benchmarked_launch_shape_against_oracle(weights, max_batch, T_all, size, name):
+    """bench.py builds Detector(max_batch = detection frames x tiles per GPU): 252 for config 3 (front layers in launches
+    of 128 + 124 tile-forwards, the first dense layer as one M = 252 GEMM), 512 for one GPU's 128-frame share of
+    config 4. The same shapes here, against the oracle: YOLO grids of frames sampled across every front-layer launch
+    (model.py:50-53,119-125), then the detection lists of ALL frames and the trajectories of both association modes
+    given those grids (the flow tracker at config 3's size; its oracle is a Bellman-Ford solver, ~40 s)."""
+    import axtrack_amd
+    frames = synth.synth_frames(T_all, size, size, seed=0)
+    model = axtrack_amd.Detector(weights, max_batch=max_batch)
+    tl = axtrack_amd.Timelapse(frames, name=name)
+    P = params.load_parameters()
+    ad = axtrack_amd.inference(tl, model, None, dict(P, ASSOCIATION='hungarian'), None, None, None)
+    yolo = ad._yolo.cpu().numpy()
+    F, n_tiles = yolo.shape[:2]
+    assert F * n_tiles == max_batch
+    per_launch = 128 // n_tiles                                           # frames per front-layer launch
+    sample = sorted({0, 1, per_launch - 1, per_launch, per_launch + 1, F // 2, 2 * per_launch - 1 if 2 * per_launch - 1 < F else F - 2,
+                     F - 2, F - 1, F // 3, 2 * F // 3, 5})
+    assert len(sample) >= 8
+    worst = 0.0
+    for t in sample:
+        ref = orc.cnn_forward(weights, orc.frame_tile_stack(frames, t, ad.tile_yx))
+        np.testing.assert_allclose(yolo[t], ref, atol=CNN_ATOL, rtol=CNN_RTOL, err_msg=f'frame {t}')
+        worst = max(worst, float(np.abs(yolo[t] - ref).max()))
+    assert worst < 5e-5, worst
+    # detections of all frames + frame-to-frame association, given the HIP grids
+    ref = orc.inference(frames, weights, P=orc.DEFAULTS, yolo=list(yolo), assoc='hungarian')
+    _assert_dets_equal_oracle(ad, ref['dets'])
+    assert tracks_from_next(np.zeros(len(ad._track_flat)), ad._track_flat, ad._offs) == ref['trajs']
+    # the reference's global flow tracker on the same detector
+    am = axtrack_amd.inference(tl, model, None, dict(P, ASSOCIATION='mcf'), None, None, None)
+    assert torch.equal(am._yolo, ad._yolo)
+    _assert_dets_equal_oracle(am, ref['dets'])
+    if name == 'c3':
+        refm = orc.inference(frames, weights, P=orc.DEFAULTS, yolo=list(yolo), assoc='mcf')
+        assert am.mcf_total_cost == refm['total_cost'] and am.n_ids == len(refm['trajs'])
+        assert tracks_from_next(np.zeros(len(am._track_flat)), am._track_flat, am._offs) == refm['trajs']
+        ids, labels, info, vals = refm['ided_all']
+        df = am.IDed_dets_all
+        assert list(df.index) == [f'Axon_{i:0>3}' for i in ids]
+        assert np.array_equal(np.nan_to_num(df.to_numpy(), nan=-1), np.nan_to_num(vals, nan=-1))
+
+
+def test_libmot_rows_of_the_product_match_the_reference(golden):
+    """get_frame_dets('all', None, libmot=True) -> det2libmot_det (AxonDetections.py:280-353,754-784) of the product class
+    against the rows the reference produced (golden assoc_parts['libmot']: FrameId, Id, X, Y, Width, Height, conf)."""
+    import pandas as pd
+    import axtrack_amd
+    from axtrack_amd.detections import AxonDetections
+    g, a = golden('detect_1024'), golden('assoc_parts')
+    tl = axtrack_amd.Timelapse(np.zeros((4 + len(g['counts']), 1024, 1024), np.float32), name='synth')
+    ad = AxonDetections(None, tl, params.load_parameters(), None)
+    ad._set_detections_from_tables([pd.DataFrame({'conf': c, 'anchor_x': x, 'anchor_y': y}) for c, x, y in golden_dets(g)])
+    ad._det_tables = None                                   # rebuild the tables from the arrays, as after detect_dataset
+    rows = ad.get_frame_dets('all', None, libmot=True)
+    assert list(rows.index.names) == ['FrameId', 'Id'] and list(rows.columns) == ['X', 'Y', 'Width', 'Height', 'conf']
+    assert np.array_equal(rows.reset_index().to_numpy(dtype=np.float64), a['libmot'])
