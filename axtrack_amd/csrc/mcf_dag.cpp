@@ -14,9 +14,9 @@
 //     u_b -> v_a  for the flow-carrying transition a->b   (cost -c_ab):   hU[b] = -c_ab + hV[a]   "steal b from a"
 //     v_k -> u_k  for a used detection                     (cost -obs_k):  hV[k] = min(., -obs_k + hU[k]) "drop k"
 // The first kind is resolved inside the step of a's frame by iterating that step to a fixed point (a's alternatives
-// may in turn steal); what a single sweep cannot see -- a value lowered after an earlier step of the same sweep has
-// already read it -- is detected exactly (no arc may remain that can still be relaxed) and answered with another
-// sweep that starts from the labels reached so far. Labels only ever decrease and each is the length of a walk to T,
+// may in turn steal), the second by a pass along the tracks after the sweep; what a sweep cannot see -- a value lowered
+// after an earlier step of the same sweep has already read it -- is detected exactly (no arc may remain that can still
+// be relaxed) and answered with another sweep that starts from the labels reached so far. Labels only ever decrease and each is the length of a walk to T,
 // so the sweeps end at the exact distances (the residual network of a min-cost flow has no negative cycle).
 // Stop rule as in mcf.cpp: push while F < min_flow, or while F < max_flow and the next path is negative.
 #include <stdint.h>
@@ -88,12 +88,12 @@ struct Dag {
             if (!changed) break;
             if (it > 4 * (hi - lo) + 16) return false;
         }
-        // tails of this frame that read hU[b] of a used b whose predecessor lies in an EARLIER frame: remember what
-        // value of hU[b] would have changed their choice
+        // tails of this frame that read hU[b] of a used b: remember what value of hU[b] would have changed their choice
+        // (hU[b] may still be lowered in this sweep, at the step of b's predecessor or by the pass along the tracks)
         for (int j = lo; j < hi; ++j)
             for (int64_t e = row_ptr[j]; e < row_ptr[j + 1]; ++e) {
                 const int b = col[e];
-                if (pred_arc[b] < 0 || pred_tail[b] >= lo || (int32_t)e == succ[j]) continue;
+                if (pred_arc[b] < 0 || (int32_t)e == succ[j]) continue;
                 const int64_t v = hV[j] >= INF ? INF : hV[j] - cost[e];
                 if (v > Bb[b]) Bb[b] = v;
             }
@@ -112,8 +112,18 @@ struct Dag {
                 ++stat_steps;
                 if (!step(t, max_gap, dirty)) return false;
             }
-            for (int k = 0; k < n && !dirty; ++k)        // "drop k" read hU[k] before its predecessor's step set it
-                if (used(k) && hU[k] < INF && -obs[k] + hU[k] < hV[k] && succ[k] >= 0) dirty = true;
+            // forward pass along the tracks (cheap: used detections only): a walk that runs backwards along a track for
+            // several frames -- steal c, drop its predecessor k, drop k's predecessor ... -- is propagated in one pass;
+            // a value that a reader of the finished sweep would have used calls for another sweep
+            for (int k = 0; k < n; ++k) {
+                if (pred_arc[k] < 0) continue;
+                const int a = pred_tail[k];
+                if (hV[a] < INF) {
+                    const int64_t nv = -cost[pred_arc[k]] + hV[a];
+                    if (nv < hU[k]) { hU[k] = nv; if (nv < Bb[k]) dirty = true; }
+                }
+                if (hU[k] < INF && succ[k] >= 0 && -obs[k] + hU[k] < hV[k]) { hV[k] = -obs[k] + hU[k]; bestV[k] = REVOBS; }
+            }
             if (!dirty) return true;
             if (sweep > 2 * F + 16) return false;
         }

@@ -263,3 +263,49 @@ def test_identity_hash_does_not_change_the_optimum_of_the_unperturbed_problem(go
     pure, n_arcs = _pure_cost_of(res, obs_i, en_i, ex_i, row_ptr, col, cost)
     assert res[2] == unpert[2] == 63
     assert pure == unpert[3] >> 16, f'the hash moved the config-3 optimum by {pure - (unpert[3] >> 16)} units (bound {n_arcs})'
+
+
+@pytest.mark.parametrize('seed', range(10))
+def test_sweep_solver_matches_oracle_on_random_timelapses(seed):
+    """axt_mcf_solve_dag (successive shortest paths as dynamic-programming sweeps over the frames, the host statement of a
+    GPU-mappable formulation) against the oracle's Bellman-Ford solver and the assignment-form solver: trajectories and
+    cost, with flow bounds that bind, empty frames, and dense frames where paths steal and drop detections."""
+    rng = np.random.default_rng(500 + seed)
+    F = int(rng.integers(3, 26))
+    dets = []
+    for t in range(F):
+        n = int(rng.integers(0, 4)) if seed % 3 == 0 else int(rng.integers(2, 12))
+        conf = np.sort(rng.uniform(0.55, 1.3, n).astype(np.float32))[::-1]
+        span = 120 if seed % 2 else 400                      # dense: everything links to everything
+        dets.append((conf, rng.integers(0, span, n), rng.integers(0, span, n)))
+    if sum(len(d[0]) for d in dets) == 0:
+        return
+    P = dict(orc.DEFAULTS, MCF_MIN_FLOW=int(rng.integers(0, 3)), MCF_MAX_FLOW=int(rng.integers(2, 14)))
+    row_ptr, col, length, gap, cost, offs = csr_arcs_from_oracle(dets, 400, 400, P)
+    obs_i, en_i, ex_i, _ = node_costs_from_oracle(dets, P)
+    trajs, total = orc.mcf_solve(dets, orc.all_path_matrices(dets, 400, 400), P)
+    res = hp.mcf_solve_dag(offs, obs_i, en_i, ex_i, row_ptr, col, cost, P['MCF_MIN_FLOW'], P['MCF_MAX_FLOW'])
+    ref = hp.mcf_solve(obs_i, en_i, ex_i, row_ptr, col, cost, P['MCF_MIN_FLOW'], P['MCF_MAX_FLOW'])
+    if trajs is None:
+        assert res is None and ref is None
+        return
+    assert res[3] == total == ref[3] and tracks_from_next(res[0], res[1], offs) == trajs
+    assert np.array_equal(res[0], ref[0]) and np.array_equal(res[1], ref[1])
+
+
+def test_sweep_solver_on_a_slice_of_config_3():
+    """48 frames of the config-3 detections (3.7 k detections, 100 k arcs, every augmenting path steals and drops dozens
+    of detections): same optimum as the assignment-form solver."""
+    from helpers import c3_network
+    obs_i, en_i, ex_i, row_ptr, col, cost, offs, _ = c3_network()
+    F = 48
+    n = int(offs[F])
+    m = int(row_ptr[n])
+    keep = col[:m] < n
+    rp = np.zeros(n + 1, np.int64)
+    tails = np.repeat(np.arange(n), np.diff(row_ptr[:n + 1]))
+    rp[1:] = np.cumsum(np.bincount(tails[keep], minlength=n))
+    args = (obs_i[:n], en_i[:n], ex_i[:n], rp, col[:m][keep], cost[:m][keep])
+    ref = hp.mcf_solve(*args, 5, 450)
+    res = hp.mcf_solve_dag(offs[:F + 1], *args, 5, 450)
+    assert res[2] == ref[2] and res[3] == ref[3] and np.array_equal(res[0], ref[0]) and np.array_equal(res[1], ref[1])
