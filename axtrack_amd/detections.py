@@ -342,9 +342,9 @@ class AxonDetections(object):
         """_get_astar_path_distances(_compute_detections_astar_paths()) (AxonDetections.py:526-585,717-752):
         dict '{name}_t:{t:03}-t:{t_bef:03}' -> int array [N_t_bef, N_t], computed on the GPU per pair."""
         cnt = self._host_dets()[0]
-        mask = self._mask_dev()
         out = {}
         for t in range(len(self)):
+            mask = self._mask_dev(t)                       # _get_maskweights(t), AxonDetections.py:557
             for t_bef in range(t - 1, t - (self.P['MCF_MAX_NUM_MISSES'] + 2), -1):
                 if t_bef < 0:
                     continue
@@ -399,7 +399,7 @@ class AxonDetections(object):
         uses). On a masked grid the GPU search walks back from every target along its distance field
         (axt_path_cells)."""
         from scipy import sparse
-        if self.dataset.mask2d is not None:
+        if self.dataset.masked:
             return self._masked_dets_paths()
         dists = self.astar_dists()
         cnt, _, x, y = self._host_dets()
@@ -438,10 +438,10 @@ class AxonDetections(object):
         back from every detection of t (hotpath.path_cells)."""
         from scipy import sparse
         cnt = self._host_dets()[0]
-        grid = self._mask_dev()
         H, W = self.dataset.sizey, self.dataset.sizex
         out = {}
         for t in range(len(self)):
+            grid = self._mask_dev(t)
             for t_bef in range(t - 1, t - (self.P['MCF_MAX_NUM_MISSES'] + 2), -1):
                 if t_bef < 0:
                     continue
@@ -486,7 +486,7 @@ class AxonDetections(object):
         results = []
         # masked grid: the exact path lengths once, for every threshold of the grid (the reference reads its path cache
         # in every iteration, :882); all-ones masks have closed-form lengths
-        lengths = self._length_table_from_dists(self.astar_dists()) if self.dataset.mask2d is not None else None
+        lengths = self._length_table_from_dists(self.astar_dists()) if self.dataset.masked else None
         try:
             for ec in edge_cost_thr_values:
                 for eec in entry_exit_cost_values:
@@ -514,14 +514,68 @@ class AxonDetections(object):
                                            box=self.axon_box_size)
         return self._hist
 
-    def _mask_dev(self):
-        """The timelapse's mask as a device grid handle (bit rows + connected components), built once."""
-        m = self.dataset.mask2d
+    def _mask_dev(self, t=None):
+        """The mask as a device grid handle (bit rows + connected components), built once per distinct mask. A static
+        mask has one grid; with a time-varying mask `t` selects the grid of the paths that end in detection frame t
+        (Timelapse.mask_groups: the reference's mask[t], frame-index quirk included unless
+        parameters['REPRODUCE_MASK_FRAME_QUIRK'] is False)."""
+        ds = self.dataset
+        if ds.mask3d is not None:
+            grids, index = self._mask_grids()
+            if t is None:
+                raise ValueError('the mask changes over time: a frame index is needed')
+            return grids[index[t]]
+        m = ds.mask2d
         if m is None:
             return None
-        if getattr(self.dataset, '_grid', None) is None or self.dataset._grid.conn8 != self.conn8:
-            self.dataset._grid = hp.Grid(m, self.conn8, self.device)
-        return self.dataset._grid
+        if getattr(ds, '_grid', None) is None or ds._grid.conn8 != self.conn8:
+            ds._grid = hp.Grid(m, self.conn8, self.device)
+        return ds._grid
+
+    def _mask_grids(self):
+        """Time-varying mask: (grids, index i32 [frames]) -- one device grid per distinct mask, kept with the timelapse."""
+        ds = self.dataset
+        quirk = bool(self.P.get('REPRODUCE_MASK_FRAME_QUIRK', True))
+        key = (self.conn8, quirk)
+        if getattr(ds, '_grids', None) is None or ds._grids[0] != key:
+            masks, index = ds.mask_groups(quirk)
+            ds._grids = (key, [None if m.all() else hp.Grid(m, self.conn8, self.device) for m in masks], index)
+        return ds._grids[1], ds._grids[2]
+
+    def _build_arcs_time_varying(self, dmax, units, vis, src_count):
+        """Arcs under a mask that changes over time: the paths of a pair are searched on the mask of its LATER frame
+        (AxonDetections.py:557), so one pass of the arc builder per distinct mask -- restricted to the source frames that
+        have a target frame under that mask -- and of every pass the arcs whose head frame belongs to it; the union,
+        ordered by (tail, gap, head) like a single pass. Global numbering and integer costs do not depend on the pass."""
+        grids, index = self._mask_grids()
+        F, cap = self.d_x.shape
+        gaps = len(dmax)
+        dev = self.device
+        count = self.d_count
+        frame_of = torch.repeat_interleave(torch.arange(F, device=dev), count.long())
+        index_d = torch.from_numpy(index).to(dev)
+        n_det = int(frame_of.numel())
+        parts = []
+        for g, grid in enumerate(grids):
+            heads = np.nonzero(index == g)[0]
+            src = np.zeros(F, bool)
+            for gap in range(1, gaps + 1):
+                src[heads[heads >= gap] - gap] = True
+            sc = torch.where(torch.from_numpy(src).to(dev), count, torch.zeros_like(count))
+            if src_count is not None:
+                sc = torch.minimum(sc, src_count)
+            row_ptr, col, length, gap_a, cost = hp.build_arcs(self.d_x, self.d_y, count, self.dataset.sizey, self.dataset.sizex,
+                                                              dmax, units, grid, self.max_px_assoc_dist, self.conn8, vis, None, sc)
+            tail = torch.repeat_interleave(torch.arange(n_det, device=dev), (row_ptr[1:n_det + 1] - row_ptr[:n_det]))
+            keep = index_d[frame_of[col.long()]] == g
+            parts.append((tail[keep], col[keep], length[keep], gap_a[keep], cost[keep]))
+        tail, col, length, gap_a, cost = (torch.cat([p[i] for p in parts]) for i in range(5))
+        order = torch.argsort((tail << 34) | (gap_a.long() << 32) | col.long())
+        tail, col, length, gap_a, cost = tail[order], col[order], length[order], gap_a[order], cost[order]
+        row_ptr = torch.zeros(F * cap + 1, dtype=torch.int64, device=dev)
+        row_ptr[1:n_det + 1] = torch.cumsum(torch.bincount(tail, minlength=n_det), 0)
+        row_ptr[n_det + 1:] = row_ptr[n_det]
+        return row_ptr, col, length, gap_a, cost
 
     def _assign_IDs_to_detections(self):
         """AxonDetections.py:631-715 with the tracker replaced by axt_build_arcs + axt_mcf_solve
@@ -533,9 +587,12 @@ class AxonDetections(object):
         mode = P.get('ASSOCIATION', 'mcf')
         if vis_w and mode != 'mcf':
             raise NotImplementedError("MCF_VIS_SIM_WEIGHT > 0 is implemented for ASSOCIATION='mcf' only")
-        masked = self.dataset.mask2d is not None
+        masked = self.dataset.masked
+        varying = self.dataset.mask3d is not None
         shard = getattr(self, '_shard', None)           # set by gather_detections(): solve only this rank's frame pairs
         if mode == 'hungarian':
+            if varying:
+                raise NotImplementedError("a time-varying mask is implemented for ASSOCIATION='mcf' (the reference's tracker) only")
             track, n_tracks = hp.hungarian_assoc(self.d_x, self.d_y, self.d_count, self.dataset.sizey,
                                                  self.dataset.sizex, dmax, units,
                                                  int(np.rint(P['MCF_EDGE_COST_THR'] * 1e6)),
@@ -558,14 +615,20 @@ class AxonDetections(object):
             # exactly that); wider thresholds take the exact, slower search over the whole range
             len_table = self._length_table_from_dists(self.astar_dists())
         src_count = None
-        if shard is not None:
+        if shard is not None and (masked or vis is not None or len_table is not None):
             # frame-sharded: this rank builds the arc rows of its own frames, one all-gather joins them (the path
-            # searches of a masked grid are the expensive part of the association and shard with the frames)
+            # searches of a masked grid / the appearance distances are the expensive part of the association and shard
+            # with the frames). On an all-ones mask the arcs are closed-form and cheaper to rebuild on every rank than to
+            # exchange: the all-gather of the detections is then the ONLY collective before the replicated flow solve.
             src_count = torch.zeros_like(self.d_count)
             src_count[shard[0]:shard[1]] = self.d_count[shard[0]:shard[1]]
-        row_ptr, col, length, gap, cost = hp.build_arcs(self.d_x, self.d_y, self.d_count, self.dataset.sizey,
-                                                        self.dataset.sizex, dmax, units, self._mask_dev(),
-                                                        self.max_px_assoc_dist, self.conn8, vis, len_table, src_count)
+        if varying and len_table is None:
+            row_ptr, col, length, gap, cost = self._build_arcs_time_varying(dmax, units, vis, src_count)
+        else:
+            row_ptr, col, length, gap, cost = hp.build_arcs(self.d_x, self.d_y, self.d_count, self.dataset.sizey,
+                                                            self.dataset.sizex, dmax, units,
+                                                            None if varying else self._mask_dev(),
+                                                            self.max_px_assoc_dist, self.conn8, vis, len_table, src_count)
         cnt, conf, x, y = self._host_dets()
         if src_count is not None:
             from . import sharded

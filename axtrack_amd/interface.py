@@ -19,7 +19,7 @@ import torch
 from . import params as _params
 from .detections import AxonDetections
 from .hotpath import Detector
-from .timelapse import Timelapse, preprocess
+from .timelapse import Timelapse, preprocess, pad_mask
 
 
 def _load_state_dict(weights):
@@ -55,8 +55,19 @@ def setup_inference(dest_dir, print_params=False, num_workers=3, device='cuda:0'
 def prepare_input_data(imseq_fname, parameters, dest_dir, inference_data_dir, stnd_scaler, mask_fname=None,
                        use_cached_datasets='to', check_preproc=False, input_metadata={}):
     """interface.py:79-168. imseq_fname: a .tif/.npy file name inside inference_data_dir or a raw
-    uint16 array [T,H,W]; mask_fname: .npy file name, bool array or None."""
+    uint16 array [T,H,W]; mask_fname: .npy file name, bool array [H,W] or [T,H,W], or None.
+    input_metadata['pad'] = p adds p zero pixels on all four sides (interface.py:126-128, Timelapse.py:224-234).
+    use_cached_datasets: 'to' writes '{dest_dir}/{name}_dataset_cached.pkl', 'from' reads it (this package's file or
+    one the reference wrote) instead of preprocessing, None does neither (Timelapse.py:435-449).
+    check_preproc=True compares with the training data's statistics by plotting (interface.py:159-167): the plotting
+    side is out of scope, so it raises."""
     name = input_metadata.get('name', 'timelapse')
+    if check_preproc:
+        raise NotImplementedError('check_preproc plots against train_preproc_data.csv, an external asset (interface.py:159-167)')
+    if use_cached_datasets not in ('to', 'from', None):
+        raise ValueError(f"use_cached_datasets must be 'to', 'from' or None, got {use_cached_datasets!r}")
+    if use_cached_datasets == 'from':
+        return Timelapse.from_cache(dest_dir, name, device=parameters['DEVICE'])
     if isinstance(imseq_fname, str):
         path = os.path.join(inference_data_dir, imseq_fname)
         if path.endswith('.npy'):
@@ -74,13 +85,20 @@ def prepare_input_data(imseq_fname, parameters, dest_dir, inference_data_dir, st
         mask = np.load(os.path.join(inference_data_dir, mask_fname))
     elif mask_fname is not None and not isinstance(mask_fname, str):
         mask = np.asarray(mask_fname)
+    pad = input_metadata.get('pad')
+    pad = [pad] * 4 if pad else None                                     # interface.py:126-128
     frames = preprocess(imseq, mask, offset=input_metadata.get('intensity_offset'),
                         clip=input_metadata.get('clip_intensity'), log_correct=parameters.get('LOG_CORRECT', True),
-                        scale=stnd_scaler[1][0], device=parameters['DEVICE'])
-    return Timelapse(frames, name=name, mask=mask, temporal_context=parameters['TEMPORAL_CONTEXT'],
-                     tilesize=parameters['TILESIZE'], device=parameters['DEVICE'],
-                     pixelsize=input_metadata.get('pixelsize'), dt=input_metadata.get('dt_min'),
-                     incubation_time=input_metadata.get('incubation_time_min'))
+                        scale=stnd_scaler[1][0], device=parameters['DEVICE'], pad=pad)
+    if pad:
+        mask = pad_mask(mask, pad, imseq.shape)
+    timelapse = Timelapse(frames, name=name, mask=mask, temporal_context=parameters['TEMPORAL_CONTEXT'],
+                          tilesize=parameters['TILESIZE'], device=parameters['DEVICE'],
+                          pixelsize=input_metadata.get('pixelsize'), dt=input_metadata.get('dt_min'),
+                          incubation_time=input_metadata.get('incubation_time_min'))
+    if use_cached_datasets == 'to':
+        timelapse.to_cache(dest_dir)
+    return timelapse
 
 
 def inference(timelapse, model, dest_dir, parameters, detections_cache='to', astar_paths_cache='to',

@@ -27,18 +27,84 @@ class Timelapse:
         self.sizet = self.frames.shape[0] - 2 * temporal_context
         self.sizey, self.sizex = int(self.frames.shape[1]), int(self.frames.shape[2])
         self.ytiles, self.xtiles = -(-self.sizey // tilesize), -(-self.sizex // tilesize)
+        # mask: one for the whole timelapse, or one per input frame (Timelapse.py:210-217 stacks a 2-D mask to [T,H,W];
+        # AxonDetections._get_maskweights(t) then reads mask[t], AxonDetections.py:587-598). mask2d is the static
+        # mask (None = all ones); mask3d is set only when the mask really changes over time.
+        self.mask2d, self.mask3d = None, None
         if mask is not None:
             mask = np.asarray(mask).astype(bool)
-            if mask.shape != (self.sizey, self.sizex):
-                raise ValueError('mask must be [H,W]')
-            if mask.all():
-                mask = None
-        self.mask2d = mask
+            if mask.ndim == 3:
+                if mask.shape != (self.frames.shape[0], self.sizey, self.sizex):
+                    raise ValueError(f'a time-varying mask must be [T_all,H,W] = {tuple(self.frames.shape)}, got {mask.shape}')
+                if (mask == mask[0]).all():
+                    mask = mask[0]
+            if mask.ndim == 2:
+                if mask.shape != (self.sizey, self.sizex):
+                    raise ValueError('mask must be [H,W] or [T_all,H,W]')
+                self.mask2d = None if mask.all() else mask
+            elif mask.ndim == 3:
+                self.mask3d = mask
+            else:
+                raise ValueError('mask must be [H,W] or [T_all,H,W]')
         self.pixelsize, self.dt, self.incubation_time = pixelsize, dt, incubation_time
         self.timepoints = np.arange(temporal_context, temporal_context + self.sizet)
 
     def __len__(self):
         return self.sizet
+
+    @property
+    def masked(self):
+        return self.mask2d is not None or self.mask3d is not None
+
+    def mask_groups(self, quirk=True):
+        """Time-varying masks: (list of distinct [H,W] masks, index i32 [sizet]) -- which mask the reference searches the
+        paths on that END in detection frame t. With quirk=True (default) that is mask[t], the mask of INPUT frame t:
+        _get_maskweights(t) indexes the context-padded frame list with the detection-frame index (AxonDetections.py:557,
+        598; Timelapse.py:408), two frames before the one detection frame t shows. quirk=False takes mask[t + context]."""
+        m = self.mask3d
+        keys, masks, index = {}, [], np.zeros(self.sizet, np.int32)
+        for t in range(self.sizet):
+            f = m[t if quirk else t + self.temporal_context]
+            k = f.tobytes()
+            if k not in keys:
+                keys[k] = len(masks)
+                masks.append(f)
+            index[t] = keys[k]
+        return masks, index
+
+    def to_cache(self, directory):
+        """'{name}_dataset_cached.pkl' (Timelapse._caching, Timelapse.py:435-449): the reference pickles its whole
+        __dict__ (sparse tensors of all three channels); this writes the same file name with what the hot path keeps --
+        the preprocessed frames, the mask and the metadata."""
+        import os
+        import pickle
+        os.makedirs(directory, exist_ok=True)
+        d = dict(_axtrack_amd_cache=1, name=self.name, frames=self.frames.cpu().numpy(),
+                 mask=self.mask3d if self.mask3d is not None else self.mask2d, temporal_context=self.temporal_context,
+                 tilesize=self.tilesize, pixelsize=self.pixelsize, dt=self.dt, incubation_time=self.incubation_time)
+        with open(f'{directory}/{self.name}_dataset_cached.pkl', 'wb') as file:
+            pickle.dump(d, file, protocol=4)
+
+    @classmethod
+    def from_cache(cls, directory, name, device='cuda:0'):
+        """Read '{name}_dataset_cached.pkl': this package's own format, or a file the reference wrote (its __dict__: `X` a
+        sparse tensor [T_all, 3, H, W] whose channel 0 is the preprocessed image, `mask` a list of scipy coo matrices)."""
+        import os
+        import pickle
+        fname = f'{directory}/{name}_dataset_cached.pkl'
+        assert os.path.exists(fname), f'\n\nNo cached dataset found: {fname}'
+        with open(fname, 'rb') as file:
+            d = pickle.load(file)
+        if d.get('_axtrack_amd_cache'):
+            return cls(d['frames'], name=d['name'], mask=d['mask'], temporal_context=d['temporal_context'],
+                       tilesize=d['tilesize'], device=device, pixelsize=d['pixelsize'], dt=d['dt'],
+                       incubation_time=d['incubation_time'])
+        X = d['X']
+        X = X.to_dense() if X.is_sparse else X
+        mask = np.stack([np.asarray(m.todense()) if hasattr(m, 'todense') else np.asarray(m) for m in d['mask']]).astype(bool)
+        return cls(X[:, 0].contiguous(), name=d.get('name', name), mask=mask, temporal_context=d.get('temporal_context', 2),
+                   tilesize=d.get('tilesize', 512), device=device, pixelsize=d.get('pixelsize'), dt=d.get('dt'),
+                   incubation_time=d.get('incubation_time'))
 
     @property
     def tile_yx(self):
@@ -73,13 +139,16 @@ class Timelapse:
         return self.frames.device
 
 
-def preprocess(imseq, mask=None, offset=121, clip=55, log_correct=True, scale=0.015176106, device='cuda:0'):
+def preprocess(imseq, mask=None, offset=121, clip=55, log_correct=True, scale=0.015176106, device='cuda:0', pad=None):
     """Dense preprocessing of a raw uint16 timelapse as Timelapse._read_tiff / _clip_image_values /
     _log_adjust_image / _standardize do it (Timelapse.py:205-326), as one fused HIP pass
     (axt_preprocess_u16): u16 -> f32 in [0,1], mask, subtract offset/2^16 and clamp at 0, zero below
     clip/2^16, log2(1+x), divide by the train-set std. `img_as_float32` and `adjust_log` are skimage
     functions that are absent here: their arithmetic (x * (1/65535), log2(1+x)) is restated from the
-    published skimage 0.18 behaviour, PARITY UNPINNED (a "next" row)."""
+    published skimage 0.18 behaviour, PARITY UNPINNED (a "next" row).
+    mask: [H,W] or one per frame [T,H,W] (Timelapse.py:210-217). pad: None or (top, right, bottom, left) -- zero
+    margins added after masking and offsetting (Timelapse.py:224-234); zero stays zero through the clip, the log and
+    the scaling, so the margins are added to the finished frames. Returns f32 [T, H + top + bottom, W + left + right]."""
     from . import hotpath as hp
     a = np.asarray(imseq)
     if a.dtype != np.uint16:
@@ -87,5 +156,27 @@ def preprocess(imseq, mask=None, offset=121, clip=55, log_correct=True, scale=0.
     raw = torch.from_numpy(np.ascontiguousarray(a).view(np.int16)).to(device)
     off = 0.0 if not offset else (offset / 2 ** 16 if isinstance(offset, int) else float(offset))
     lo = 0.0 if not clip else (clip / 2 ** 16 if isinstance(clip, int) else float(clip))
-    m = None if mask is None else torch.from_numpy(np.ascontiguousarray(np.asarray(mask).astype(np.uint8)))
-    return hp.preprocess_u16(raw, m, off, lo, bool(log_correct), float(scale))
+    m = None
+    if mask is not None:
+        mk = np.asarray(mask).astype(bool)
+        if mk.ndim == 3:                      # a mask per frame: zero the raw counts, which is what masking the floats does
+            if mk.shape != a.shape:
+                raise ValueError(f'a time-varying mask must match the timelapse {a.shape}, got {mk.shape}')
+            raw = raw * torch.from_numpy(mk).to(device=device, dtype=torch.int16)
+        else:
+            m = torch.from_numpy(np.ascontiguousarray(mk.astype(np.uint8)))
+    out = hp.preprocess_u16(raw.contiguous(), m, off, lo, bool(log_correct), float(scale))
+    if pad is not None and any(pad):
+        top, right, bottom, left = (int(v) for v in pad)
+        out = torch.nn.functional.pad(out, (left, right, top, bottom)).contiguous()
+    return out
+
+
+def pad_mask(mask, pad, shape):
+    """The mask of a padded timelapse (Timelapse.py:231-234): zeros in the margins; an absent mask becomes the all-ones
+    mask of the unpadded frame, so the margins are off the mask for the path searches exactly as in the reference."""
+    top, right, bottom, left = (int(v) for v in pad)
+    T, H, W = shape
+    m = np.ones((H, W), bool) if mask is None else np.asarray(mask).astype(bool)
+    width = ((top, bottom), (left, right))
+    return np.pad(m, width if m.ndim == 2 else ((0, 0),) + width)

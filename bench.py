@@ -12,8 +12,8 @@ config "c3" (512x512x256, detection + association); "c2" is detection only.
 
 Multi-GPU (weak scaling): the timelapse has N x 252 detection frames, rank r detects its own
 contiguous block (reading a 2-frame halo), ONE all-gather of the detection lists over RCCL, then the
-association (Hungarian: every rank its own frame pairs + one MAX all-reduce; min-cost flow: every rank its own frames'
-arc rows + one all-gather of the arcs, replicated solve), and
+association (Hungarian: every rank its own frame pairs + one MAX all-reduce of the links; min-cost flow: the closed-form
+arcs of an all-ones mask are rebuilt on every rank, so the all-gather stays the only collective before the replicated solve), and
 every rank materialises its own block of IDed_dets_all (its frames x the identities alive in them).
 
 Prints ONE JSON line on rank 0 (contract: see the task description), with

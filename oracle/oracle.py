@@ -98,7 +98,11 @@ def preprocess(raw_u16, mask=None, offset=0.0, clip_lower=0.0, log_correct=True,
     skimage functions absent here, restated from their published behaviour: PARITY UNPINNED."""
     x = np.multiply(raw_u16, 1. / 65535, dtype=np.float32)
     if mask is not None:
-        x[:, ~np.asarray(mask, bool)] = 0
+        m = np.asarray(mask, bool)
+        if m.ndim == 2:
+            x[:, ~m] = 0
+        else:
+            x[~m] = 0                                    # a mask per frame (Timelapse.py:214-217)
     if offset:
         x -= np.float32(offset)
         x[x < 0] = 0
@@ -307,14 +311,29 @@ def path_matrix(src, dst, H, W, mask=None, max_dist=MAX_PX_ASSOC_DIST, conn8=Fal
     return D
 
 
-def all_path_matrices(dets, H, W, mask=None, max_misses=1, name='synth', **kw):
-    """dict keyed like the reference: '{name}_t:{t:03}-t:{t_bef:03}' (:554,563)."""
+def mask_of_frame(mask, t, quirk=True, ctx=2):
+    """The mask the reference searches paths on for the pairs that END in detection frame t (_get_maskweights(t),
+    AxonDetections.py:557,587-598). A [H,W] mask holds for every frame (Timelapse.py:214-215). A [T_all,H,W] mask is
+    indexed with the DETECTION frame index t although dataset.mask lists the context-padded input frames
+    (Timelapse.py:408), i.e. it takes the mask of input frame t, not of t + ctx where detection frame t sits --
+    reproduced by default (quirk=True)."""
+    if mask is None:
+        return None
+    mask = np.asarray(mask)
+    if mask.ndim == 2:
+        return mask
+    return mask[t if quirk else t + ctx]
+
+
+def all_path_matrices(dets, H, W, mask=None, max_misses=1, name='synth', mask_quirk=True, **kw):
+    """dict keyed like the reference: '{name}_t:{t:03}-t:{t_bef:03}' (:554,563). mask: None, [H,W] or [T_all,H,W]."""
     out = {}
     for t in range(len(dets)):
+        m = mask_of_frame(mask, t, mask_quirk)
         for t_bef in range(t - 1, t - (max_misses + 2), -1):
             if t_bef < 0:
                 continue
-            out[f'{name}_t:{t:0>3}-t:{t_bef:0>3}'] = path_matrix(dets[t_bef], dets[t], H, W, mask, **kw)
+            out[f'{name}_t:{t:0>3}-t:{t_bef:0>3}'] = path_matrix(dets[t_bef], dets[t], H, W, m, **kw)
     return out
 
 
@@ -579,7 +598,8 @@ def inference(frames, sd, mask=None, P=DEFAULTS, name='synth', yolo=None, assoc=
         tables = ided_tables(trajs, dets)
         return dict(dets=dets, yolo=yolo, D=None, trajs=trajs, total_cost=None, tables=tables,
                     ided_all=ided_dets_all(tables))
-    D = all_path_matrices(dets, frames.shape[1], frames.shape[2], mask, P['MCF_MAX_NUM_MISSES'], name)
+    D = all_path_matrices(dets, frames.shape[1], frames.shape[2], mask, P['MCF_MAX_NUM_MISSES'], name,
+                          mask_quirk=P.get('REPRODUCE_MASK_FRAME_QUIRK', True))
     images = [frames[t + 2] for t in range(len(dets))] if P.get('MCF_VIS_SIM_WEIGHT', 0) else None   # the centre frames
     trajs, total = mcf_solve(dets, D, P, name, images)
     tables = ided_tables(trajs, dets) if trajs else None

@@ -1,5 +1,7 @@
 """Parity of the HIP hot path (through the C ABI) against the golden vectors captured from the
 reference and against the CPU oracle. Run on the MI355X box: pytest -m gpu."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1241,3 +1243,99 @@ def test_libmot_rows_of_the_product_match_the_reference(golden):
     rows = ad.get_frame_dets('all', None, libmot=True)
     assert list(rows.index.names) == ['FrameId', 'Id'] and list(rows.columns) == ['X', 'Y', 'Width', 'Height', 'conf']
     assert np.array_equal(rows.reset_index().to_numpy(dtype=np.float64), a['libmot'])
+
+
+# ----------------------------------------------------------------------------------------- masks over time, pad, dataset cache
+@pytest.mark.parametrize('quirk', [True, False])
+def test_inference_with_a_mask_that_changes_over_time(weights, quirk):
+    """Timelapse.py:210-217 takes a mask per input frame; the paths of a frame pair are searched on the mask of its later
+    frame -- indexed with the detection-frame number, which is the mask of the input frame two steps earlier
+    (AxonDetections.py:557,587-598; reproduced by default, REPRODUCE_MASK_FRAME_QUIRK=False uses the centre frame). Three
+    masks over 13 input frames (corridors, shifted corridors, all ones): arcs, optimum and path matrices equal the
+    oracle's."""
+    import axtrack_amd
+    T_all = 13
+    frames = synth.synth_frames(T_all, 512, 512, seed=31)
+    m0 = synth.corridor_mask(512, 512, width=40, pitch=128)
+    m1 = np.roll(synth.corridor_mask(512, 512, width=56, pitch=160), 23, axis=1)
+    mask = np.stack([m0] * 4 + [m1] * 4 + [np.ones_like(m0)] * 2 + [m1] * 3)
+    P = dict(params.load_parameters(), REPRODUCE_MASK_FRAME_QUIRK=quirk)
+    model = axtrack_amd.Detector(weights, max_batch=16)
+    tl = axtrack_amd.Timelapse(frames, name='synth', mask=mask)
+    assert tl.mask3d is not None and tl.mask2d is None
+    masks, index = tl.mask_groups(quirk)
+    assert len(masks) == 3 and list(index) == (([0] * 4 + [1] * 4 + [2]) if quirk else ([0] * 2 + [1] * 4 + [2] * 2 + [1]))
+    ad = axtrack_amd.inference(tl, model, None, P, None, None, None)
+    yolo = ad._yolo.cpu().numpy()
+    ref = orc.inference(frames, weights, mask=mask, P=dict(orc.DEFAULTS, REPRODUCE_MASK_FRAME_QUIRK=quirk), yolo=list(yolo))
+    got = tracks_from_next(np.zeros(len(ad._track_flat)), ad._track_flat, ad._offs)
+    assert got == ref['trajs'] and ad.mcf_total_cost == ref['total_cost']
+    dists = ad.astar_dists()
+    assert dists.keys() == ref['D'].keys()
+    for k in dists:
+        assert np.array_equal(dists[k], ref['D'][k]), k
+    # a [T,H,W] mask that never changes is a static mask
+    tl2 = axtrack_amd.Timelapse(frames, name='synth', mask=np.stack([m0] * T_all))
+    assert tl2.mask3d is None and np.array_equal(tl2.mask2d, m0)
+    with pytest.raises(NotImplementedError):
+        axtrack_amd.inference(tl, model, None, dict(P, ASSOCIATION='hungarian'), None, None, None)
+    with pytest.raises(ValueError):
+        axtrack_amd.Timelapse(frames, name='synth', mask=mask[:5])
+
+
+def test_prepare_input_data_pad_mask_per_frame_and_dataset_cache(weights, tmp_path):
+    """prepare_input_data (interface.py:79-168): input_metadata['pad'] adds zero margins to image and mask after masking
+    and offsetting (Timelapse.py:224-234), a mask may come per frame, use_cached_datasets writes / reads
+    '{name}_dataset_cached.pkl' (Timelapse.py:435-449; also a file in the reference's own layout). Frames against the
+    oracle's preprocessing, then the whole path on the padded timelapse against the oracle."""
+    import pickle
+    import axtrack_amd
+    from scipy import sparse
+    rng = np.random.default_rng(3)
+    T, H, W, pad = 9, 400, 400, 56
+    base = synth.synth_frames(T, H, W, seed=12)
+    raw = np.clip((2.0 ** (base * 0.015176106) - 1.0) * 65535.0 + 121.0 * (base > 0), 0, 65535).astype(np.uint16)
+    m = synth.corridor_mask(H, W, width=60, pitch=150)
+    mask = np.stack([m] * 5 + [np.roll(m, 31, axis=0)] * 4)
+    P = params.load_parameters()
+    meta = {'name': 'padded', 'intensity_offset': 121, 'clip_intensity': 55, 'pad': pad}
+    np.save(tmp_path / 'mask.npy', mask)
+    np.save(tmp_path / 'raw.npy', raw)
+    tl = axtrack_amd.prepare_input_data('raw.npy', P, str(tmp_path), str(tmp_path), params.DEPLOYED_STND_SCALER, 'mask.npy',
+                                        use_cached_datasets='to', input_metadata=meta)
+    ref = orc.preprocess(raw, mask, 121 / 2 ** 16, 55 / 2 ** 16, True, 0.015176106)
+    ref = np.pad(ref, ((0, 0), (pad, pad), (pad, pad)))
+    got = tl.frames.cpu().numpy()
+    assert got.shape == (T, H + 2 * pad, W + 2 * pad) == ref.shape
+    assert np.array_equal(got == 0, ref == 0)
+    np.testing.assert_allclose(got, ref, rtol=3e-7, atol=0)
+    ref_mask = np.pad(mask, ((0, 0), (pad, pad), (pad, pad)))
+    assert np.array_equal(tl.mask3d, ref_mask)
+    # no mask + pad: the margins are off the mask, as in the reference
+    tl_nomask = axtrack_amd.prepare_input_data(raw, P, str(tmp_path), str(tmp_path), params.DEPLOYED_STND_SCALER, None,
+                                               use_cached_datasets=None, input_metadata=dict(meta, name='nomask'))
+    assert tl_nomask.mask2d is not None and tl_nomask.mask2d[pad:-pad, pad:-pad].all() and tl_nomask.mask2d.sum() == H * W
+    assert not os.path.exists(tmp_path / 'nomask_dataset_cached.pkl')
+    # cache round trip
+    again = axtrack_amd.prepare_input_data('raw.npy', P, str(tmp_path), str(tmp_path), params.DEPLOYED_STND_SCALER, 'mask.npy',
+                                           use_cached_datasets='from', input_metadata=meta)
+    assert torch.equal(again.frames, tl.frames) and np.array_equal(again.mask3d, tl.mask3d) and again.name == 'padded'
+    # a cache in the reference's layout: X sparse [T,3,H,W] (channel 0 = image), mask a list of coo matrices
+    X = torch.zeros((T, 3) + got.shape[1:])
+    X[:, 0] = torch.from_numpy(got)
+    with open(tmp_path / 'theirs_dataset_cached.pkl', 'wb') as f:
+        pickle.dump(dict(name='theirs', X=X.to_sparse(), mask=[sparse.coo_matrix(k) for k in ref_mask], temporal_context=2,
+                         tilesize=512, sizet=T - 4), f)
+    theirs = axtrack_amd.prepare_input_data(None, P, str(tmp_path), str(tmp_path), params.DEPLOYED_STND_SCALER, None,
+                                            use_cached_datasets='from', input_metadata={'name': 'theirs'})
+    assert torch.equal(theirs.frames, tl.frames) and np.array_equal(theirs.mask3d, tl.mask3d)
+    with pytest.raises(NotImplementedError):
+        axtrack_amd.prepare_input_data(raw, P, str(tmp_path), str(tmp_path), params.DEPLOYED_STND_SCALER, None,
+                                       check_preproc=True, input_metadata=meta)
+    # the whole path on the padded timelapse
+    model = axtrack_amd.Detector(weights, max_batch=8)
+    ad = axtrack_amd.inference(tl, model, None, dict(P, MCF_MIN_FLOW=1), None, None, None)
+    refi = orc.inference(got, weights, mask=ref_mask, P=dict(orc.DEFAULTS, MCF_MIN_FLOW=1), yolo=list(ad._yolo.cpu().numpy()))
+    _assert_dets_equal_oracle(ad, refi['dets'])
+    assert tracks_from_next(np.zeros(len(ad._track_flat)), ad._track_flat, ad._offs) == refi['trajs']
+    assert ad.mcf_total_cost == refi['total_cost']
