@@ -335,7 +335,23 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_s2_k1(
 
     const int Hout = Hin / 2;
     const int tiles_x = Hout / G::TW, ntile = tiles_x * (Hout / G::TH);
-    const WorkRange wr = my_work(ntile * B);
+    // Work order. Block 1: the XCD-contiguous (item, tile) list of my_work. Block 0 reads frames t..t+4 for item t, so
+    // consecutive items share four of their five frames -- but only while those are still in the XCD's 4 MB L2, and a
+    // whole item streams 5 MB through it. Every XCD therefore takes a contiguous range of items and walks it one
+    // row of tiles at a time: (row of tiles, item, tile in the row). The band of a frame that a row of tiles needs
+    // (35 input rows, 70 KB) is then fetched once per XCD, for all the items that use it (20 frames x 70 KB in flight).
+    int it_begin = 0, ni = B;
+    WorkRange wr;
+    if constexpr (FIRST) {
+        const int xcd = blockIdx.x & 7;
+        it_begin = (int)((long)xcd * B / 8);
+        ni = (int)((long)(xcd + 1) * B / 8) - it_begin;
+        wr.begin = blockIdx.x >> 3;
+        wr.end = ni * ntile;
+        wr.step = gridDim.x >> 3;
+    } else {
+        wr = my_work(ntile * B);
+    }
 
     {
         constexpr int NW4 = CIN * 9 * 4 * NGP / 4;
@@ -380,8 +396,17 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_s2_k1(
     unsigned nxt_valid = 0;
     __amdgpu_buffer_rsrc_t src_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, 0, 0x00020000);
     auto decode_plan = [&](int w) {
-        const int tile = w % ntile;
-        nxt_b = w / ntile;
+        int tile;
+        if constexpr (FIRST) {
+            const int per_band = ni * tiles_x;
+            const int band = w / per_band, r = w - band * per_band;
+            const int ib = r / tiles_x;
+            nxt_b = it_begin + ib;
+            tile = band * tiles_x + (r - ib * tiles_x);
+        } else {
+            tile = w % ntile;
+            nxt_b = w / ntile;
+        }
         nxt_y0 = (tile / tiles_x) * G::TH;
         nxt_x0 = (tile % tiles_x) * G::TW;
         int lim_y, lim_x;
