@@ -283,6 +283,201 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(
 }
 
 // ------------------------------------------------------------------------------------------------
+// conv3x3_bf16x3: the stride-1 blocks with 80 output channels on the bf16 matrix pipe -- OPT-IN arithmetic
+// (parameters['CNN_ARITH'] = 'bf16x3'; the default and every headline number stay on the f32 kernels above).
+//   Every f32 operand is split exactly into three bf16 terms, x = hi + mid + lo (8 + 8 + 8 mantissa bits), and a product
+//   x*w is taken as the six partial products of weight >= 2^-16: hi*hi, hi*mid, mid*hi, hi*lo, mid*mid, lo*hi. Each
+//   bf16 x bf16 product is exact in f32 and the accumulation is f32, so one product carries a relative error of about
+//   3 * 2^-24 -- the size of an f32 rounding -- at 6/16 of the f32 pipe's cycles per multiply-add
+//   (v_mfma_f32_16x16x32_bf16: 16 x 16 outputs x 32 k in 16 cycles against 16 x 16 x 4 in 32).
+//   Same tiling as conv3x3_mfma: 16 x 16 output pixels per workgroup, wave w owns rows 4w..4w+3 and all 80 channels
+//   (4 x 5 accumulator tiles), one wave per SIMD with the whole register file (512): the next chunk's global loads
+//   (24 + 76 registers) wait in registers behind the MFMAs.
+//   K runs in chunks of 16 input channels. One MFMA k-step (32 k) = four "pairs" of (tap, 8-channel half): lane (p, q)
+//   holds pixel p's 8 channels of pair q as ONE 16-byte LDS read. A chunk has 9 taps x 2 halves = 18 pairs = 4.5
+//   k-steps, padded to 5 with zero weights (10 %).
+//   LDS: patch [plane hi|mid|lo][half][18 rows][18 cols][8 ch] bf16, halves padded to a multiple of 256 B so that the two
+//   halves a 16-lane read group touches fall on disjoint banks; weights [k-step][plane][q][80 n][8 k] bf16, copied
+//   verbatim from the packed image (axt_pack_bf16x3). The f32 -> 3 x bf16 split of the activations happens on the way
+//   from the prefetch registers into LDS (v_cvt_pk_bf16_f32, round to nearest even; the residuals are exact in f32).
+//   Input and output stay f32 NCHW, so the layer is interchangeable with conv3x3_mfma block by block.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+struct GeoB3 {
+    static constexpr int CCH = 16, MT = 4, NT = 5, PH = 18, PW = 18, KS = 5;
+    static constexpr int HALF_B = ((PH * PW * 16 + 255) / 256) * 256;      // 5376 bytes
+    static constexpr int PLANE_B = 2 * HALF_B;
+    static constexpr int PATCH_B = 3 * PLANE_B;                             // 32256
+    static constexpr int WQ_B = NT * 16 * 16;                               // one (k-step, plane, q) block: 80 n x 16 B
+    static constexpr int WSTEP_B = 3 * 4 * WQ_B;
+    static constexpr int WCHUNK_B = KS * WSTEP_B;                           // 76800
+    static constexpr int LDS_B = PATCH_B + WCHUNK_B;                        // 109056
+    static constexpr int DUMMY = PH * PW * 16;                              // first padding byte of half 0: never read
+};
+
+// x[0..7] -> the three bf16 planes, 8 values each (exact: x = hi + mid + lo unless lo underflows)
+__device__ __forceinline__ void split_bf16x3(const float (&x)[8], u32x4 &H, u32x4 &M, u32x4 &L)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = x[2 * i], b = x[2 * i + 1];
+        const bf16x2 h = {(__bf16)a, (__bf16)b};
+        const float ra = a - (float)h[0], rb = b - (float)h[1];
+        const bf16x2 m = {(__bf16)ra, (__bf16)rb};
+        const float sa = ra - (float)m[0], sb = rb - (float)m[1];
+        const bf16x2 l = {(__bf16)sa, (__bf16)sb};
+        H[i] = __builtin_bit_cast(unsigned, h);
+        M[i] = __builtin_bit_cast(unsigned, m);
+        L[i] = __builtin_bit_cast(unsigned, l);
+    }
+}
+
+template <int CIN, bool POOL>
+__global__ __launch_bounds__(256, 1) void conv3x3_bf16x3(
+    const float *__restrict__ in,       // activations [B,CIN,Hin,Hin] f32
+    const unsigned *__restrict__ wpk,   // packed weights: per chunk the LDS image [KS][3][4][80][8] bf16
+    const float *__restrict__ bias,     // folded bias [80]
+    float *__restrict__ out,            // [B,80,Hout,Hout] f32
+    int Hin, int B)
+{
+    using G = GeoB3;
+    constexpr int COUT = 80, MT = G::MT, NT = G::NT, PH = G::PH, PW = G::PW;
+    constexpr int NCHUNK = (CIN + G::CCH - 1) / G::CCH;
+
+    extern __shared__ __attribute__((aligned(256))) unsigned char smem_b[];
+    unsigned char *patch = smem_b;
+    unsigned char *wl = smem_b + G::PATCH_B;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 15, q = lane >> 4;
+    const int tiles_x = Hin / 16, ntile = tiles_x * tiles_x;
+    int w;
+    {
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int qq = nwg >> 3, rr = nwg & 7;
+        w = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + slot;
+    }
+    const int tile = w % ntile, b = w / ntile;
+    const int y0 = (tile / tiles_x) * 16, x0 = (tile % tiles_x) * 16;
+    const int cstride = Hin * Hin;
+    const int Hout = POOL ? Hin / 2 : Hin;
+
+    // staging plan of the patch: item e = tid + k*256 is (half h, row r, col): 8 channels of one pixel. The global side
+    // is eight buffer loads (one per channel, coalesced along the row); pixels outside the image carry an
+    // out-of-range offset and channels beyond CIN fall behind the descriptor's range: both read as the zero padding.
+    constexpr int NITEM = 2 * PH * PW;                 // 648
+    constexpr int NPE = (NITEM + 255) / 256;           // 3
+    unsigned gofs[NPE], lofs[NPE];
+#pragma unroll
+    for (int k = 0; k < NPE; ++k) {
+        const int e = tid + k * 256;
+        const int h = e / (PH * PW), rem = e - h * (PH * PW);
+        const int r = rem / PW, col = rem - r * PW;
+        const int gy = y0 - 1 + r, gx = x0 - 1 + col;
+        const bool in_patch = e < NITEM;
+        const bool ok = in_patch && gy >= 0 && gy < Hin && gx >= 0 && gx < Hin;
+        gofs[k] = ok ? (unsigned)((8 * h * cstride + gy * Hin + gx) * 4) : kOobOffset;
+        lofs[k] = in_patch ? (unsigned)(h * G::HALF_B + (r * PW + col) * 16) : (unsigned)G::DUMMY;
+    }
+    constexpr int NW16 = G::WCHUNK_B / 16;             // 4800 16-byte elements per chunk
+    constexpr int NWE = (NW16 + 255) / 256;            // 19
+    float pv[NPE][8];
+    u32x4 wv[NWE];
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(in) + (long)b * CIN * cstride, 0, CIN * cstride * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned *>(wpk), 0, NCHUNK * G::WCHUNK_B, 0x00020000);
+    auto load_chunk = [&](int chunk) {
+        const unsigned cbase = (unsigned)(chunk * G::CCH * cstride * 4);
+#pragma unroll
+        for (int k = 0; k < NPE; ++k)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const unsigned off = gofs[k] == kOobOffset ? kOobOffset : gofs[k] + cbase + (unsigned)(i * cstride * 4);
+                pv[k][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, (int)off, 0, 0));
+            }
+        const unsigned wbase = (unsigned)(chunk * G::WCHUNK_B);
+#pragma unroll
+        for (int k = 0; k < NWE; ++k) {
+            const int e = tid + k * 256;
+            wv[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, e < NW16 ? (int)(wbase + e * 16) : (int)kOobOffset, 0, 0));
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int k = 0; k < NPE; ++k) {
+            u32x4 H, M, L;
+            split_bf16x3(pv[k], H, M, L);
+            *reinterpret_cast<u32x4 *>(patch + lofs[k]) = H;
+            *reinterpret_cast<u32x4 *>(patch + G::PLANE_B + lofs[k]) = M;
+            *reinterpret_cast<u32x4 *>(patch + 2 * G::PLANE_B + lofs[k]) = L;
+        }
+#pragma unroll
+        for (int k = 0; k < NWE; ++k) {
+            const int e = tid + k * 256;
+            if (k + 1 < NWE || e < NW16) *reinterpret_cast<u32x4 *>(wl + e * 16) = wv[k];
+        }
+    };
+    float bias_v[NT];
+    load_bias<COUT, NT>(bias, 0, p, bias_v);
+
+    const unsigned a_lane = (unsigned)((q & 1) * G::HALF_B + ((wave * MT) * PW + p) * 16);
+    const unsigned b_lane = (unsigned)(q * G::WQ_B + p * 16);
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    load_chunk(0);
+    for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+        if (chunk) __syncthreads();          // every wave is done reading the previous chunk
+        store_chunk();
+        __syncthreads();
+        if (chunk + 1 < NCHUNK) load_chunk(chunk + 1);
+#pragma unroll
+        for (int s = 0; s < G::KS; ++s) {
+            // pairs 4s + q: tap (4s + q) / 2 (the padding pairs of the last step re-read tap 8: finite values, zero weights)
+            constexpr int kLast = 8;
+            const int tap_a = 2 * s < kLast ? 2 * s : kLast, tap_b = 2 * s + 1 < kLast ? 2 * s + 1 : kLast;
+            const unsigned off_a = (unsigned)(((tap_a / 3) * PW + tap_a % 3) * 16);
+            const unsigned off_b = (unsigned)(((tap_b / 3) * PW + tap_b % 3) * 16);
+            const unsigned toff = a_lane + ((q >> 1) ? off_b : off_a);
+            bf16x8 A[3][MT];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    A[pl][m] = *reinterpret_cast<const bf16x8 *>(patch + pl * G::PLANE_B + toff + m * PW * 16);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                bf16x8 Bv[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    Bv[pl] = *reinterpret_cast<const bf16x8 *>(wl + (s * 3 + pl) * 4 * G::WQ_B + b_lane + n * 256);
+                // the six partial products, small terms first; consecutive MFMAs go to different accumulators
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0][m], Bv[2], acc[m][n], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[2][m], Bv[0], acc[m][n], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1][m], Bv[1], acc[m][n], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0][m], Bv[1], acc[m][n], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1][m], Bv[0], acc[m][n], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0][m], Bv[0], acc[m][n], 0, 0, 0);
+            }
+        }
+    }
+    conv_epilogue<COUT, POOL, MT, NT>(acc, bias_v, out, b, 0, y0, x0, wave, p, q, Hout, Hout);
+}
+
+// ------------------------------------------------------------------------------------------------
 // stride-2 conv3x3 on v_mfma_f32_4x4x1_16b_f32 (conv blocks 0 and 1).
 //   These two layers have narrow N (20 / 40 channels) and, block 0, K = 45: on 16x16x4 tiles 20 pads to 32 and 45 to
 //   48. The 4x4x1 shape (16 independent 4-pixel x 4-channel outer products per instruction, 8 cycles, the same
@@ -784,6 +979,9 @@ constexpr int kFc1Split = 32, kFc2Split = 4, kFc3Split = 4;
 struct axt_detector {
     int max_batch = 0;
     float *d_wconv[8] = {};     // packed conv weights
+    unsigned *d_wb3[8] = {};    // conv blocks 2..6 packed for conv3x3_bf16x3 (allocated on the first switch to that arithmetic)
+    std::vector<float> h_wfold[8];   // their BN-folded f32 weights [cout][cin][3][3], kept on the host for that packing
+    int arith = 0;              // 0: f32 MFMA everywhere (default) | 1: bf16x3 for the stride-1 blocks with 80 output channels
     float *d_bconv[8] = {};     // folded bias
     float *d_wfc[3] = {};       // [K][Npad]
     float *d_bfc[3] = {};
@@ -851,7 +1049,8 @@ int dev_alloc(axt_detector *d, T **p, size_t n)
 //   ((ky*3+kx) * CCH/4 + cg) * 4 + kk  <->  channel chunk*CCH + cg*4 + kk
 // stride-2 layers (conv3x3_s2_k1): [k = ci*9 + ky*3 + kx][j][NGP], channel 4g + j at position g.
 void pack_conv(int li, const float *w, const float *b, const float *gamma, const float *beta,
-               const float *mean, const float *var, std::vector<float> &wp, std::vector<float> &bp)
+               const float *mean, const float *var, std::vector<float> &wp, std::vector<float> &bp,
+               std::vector<float> *wfold = nullptr)
 {
     const ConvSpec &cs = kConv[li];
     const ConvPlan &pl = kPlan[li];
@@ -862,6 +1061,7 @@ void pack_conv(int li, const float *w, const float *b, const float *gamma, const
     const int ngp = (cs.cout / 4 + 3) / 4 * 4;
     wp.assign(s2 ? (size_t)cs.cin * 9 * 4 * ngp : (size_t)pl.ngroups * nchunk * krows * NPADW, 0.f);
     bp.assign(cs.cout, 0.f);
+    if (wfold) wfold->assign((size_t)cs.cout * cs.cin * 9, 0.f);
     for (int co = 0; co < cs.cout; ++co) {
         const double sc = (double)gamma[co] / sqrt((double)var[co] + 1e-5);
         bp[co] = (float)(((double)b[co] - (double)mean[co]) * sc + (double)beta[co]);
@@ -870,6 +1070,7 @@ void pack_conv(int li, const float *w, const float *b, const float *gamma, const
             for (int ky = 0; ky < 3; ++ky)
                 for (int kx = 0; kx < 3; ++kx) {
                     const float v = (float)((double)w[(((size_t)co * cs.cin + ci) * 3 + ky) * 3 + kx] * sc);
+                    if (wfold) (*wfold)[(((size_t)co * cs.cin + ci) * 3 + ky) * 3 + kx] = v;
                     if (s2) {
                         wp[(((size_t)ci * 9 + ky * 3 + kx) * 4 + co % 4) * ngp + co / 4] = v;
                     } else {
@@ -879,6 +1080,68 @@ void pack_conv(int li, const float *w, const float *b, const float *gamma, const
                     }
                 }
     }
+}
+
+// f32 -> bf16, round to nearest even (what v_cvt_pk_bf16_f32 does for finite values)
+inline uint16_t bf16_rne(float x)
+{
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+inline float bf16_to_f32(uint16_t h)
+{
+    const uint32_t u = (uint32_t)h << 16;
+    float x;
+    memcpy(&x, &u, 4);
+    return x;
+}
+
+// Packs the BN-folded weights [80][cin][3][3] of a stride-1 block for conv3x3_bf16x3: per chunk of 16 input channels the
+// LDS image [k-step 5][plane hi|mid|lo][q 4][n 80][8] bf16; pair 4*step + q = (tap, 8-channel half), pairs >= 18 are zero.
+void pack_bf16x3(int cin, const std::vector<float> &wfold, std::vector<uint16_t> &out)
+{
+    using G = GeoB3;
+    const int nchunk = (cin + G::CCH - 1) / G::CCH;
+    out.assign((size_t)nchunk * G::WCHUNK_B / 2, 0);
+    for (int chunk = 0; chunk < nchunk; ++chunk)
+        for (int s = 0; s < G::KS; ++s)
+            for (int q = 0; q < 4; ++q) {
+                const int j = 4 * s + q;
+                if (j >= 18) continue;
+                const int tap = j >> 1, half = j & 1, ky = tap / 3, kx = tap % 3;
+                for (int n = 0; n < 80; ++n)
+                    for (int i = 0; i < 8; ++i) {
+                        const int c = chunk * G::CCH + 8 * half + i;
+                        if (c >= cin) continue;
+                        const float v = wfold[(((size_t)n * cin + c) * 3 + ky) * 3 + kx];
+                        const uint16_t hi = bf16_rne(v);
+                        const float r1 = v - bf16_to_f32(hi);
+                        const uint16_t mid = bf16_rne(r1);
+                        const uint16_t lo = bf16_rne(r1 - bf16_to_f32(mid));
+                        const uint16_t pl[3] = {hi, mid, lo};
+                        for (int k = 0; k < 3; ++k)
+                            out[((((size_t)(chunk * G::KS + s) * 3 + k) * 4 + q) * 80 + n) * 8 + i] = pl[k];
+                    }
+            }
+}
+
+template <int CIN, bool POOL>
+int launch_conv_b3(const float *in, const unsigned *w, const float *bias, float *out, int Hin, int B, hipStream_t st)
+{
+    auto kern = conv3x3_bf16x3<CIN, POOL>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        AXT_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GeoB3::LDS_B));
+        attr_set = true;
+    }
+    AXT_REQUIRE(Hin % 16 == 0 && w != nullptr, "conv (bf16x3): map size %d not a multiple of the 16x16 tile, or weights not packed", Hin);
+    AXT_REQUIRE((double)CIN * Hin * Hin * 4 < 2.0e9, "conv (bf16x3): map too large");
+    const int nwork = (Hin / 16) * (Hin / 16) * B;
+    hipLaunchKernelGGL(kern, dim3(nwork), dim3(256), GeoB3::LDS_B, st, in, w, bias, out, Hin, B);
+    AXT_LAUNCH_CHECK();
+    return AXT_OK;
 }
 
 // persistent grids: a multiple of 8 (one slice per XCD), at most `per_cu` workgroups per CU
@@ -1009,9 +1272,10 @@ int run_front_a(axt_detector *d, const float *frames, int Hf, int Wf, int t0, in
     }
     {
         ProfSpan ps(d, st, 2, nb);
-        if ((rc = launch_conv<40, 80, true, 8, 5>(d->d_act[1], d->d_wconv[2], d->d_bconv[2],
-                                                               d->d_act[2] + (size_t)slot0 * 80 * 64 * 64, 128, 1, nb,
-                                                               st))) return rc;
+        float *dst = d->d_act[2] + (size_t)slot0 * 80 * 64 * 64;
+        rc = d->arith ? launch_conv_b3<40, true>(d->d_act[1], d->d_wb3[2], d->d_bconv[2], dst, 128, nb, st)
+                      : launch_conv<40, 80, true, 8, 5>(d->d_act[1], d->d_wconv[2], d->d_bconv[2], dst, 128, 1, nb, st);
+        if (rc) return rc;
     }
     return AXT_OK;
 }
@@ -1022,13 +1286,15 @@ int run_front_b(axt_detector *d, int nb, float *act4_out, hipStream_t st)
     int rc;
     {
         ProfSpan ps(d, st, 3, nb);
-        if ((rc = launch_conv<80, 80, false, 8, 5>(d->d_act[2], d->d_wconv[3], d->d_bconv[3], d->d_act[3],
-                                                                64, 1, nb, st))) return rc;
+        rc = d->arith ? launch_conv_b3<80, false>(d->d_act[2], d->d_wb3[3], d->d_bconv[3], d->d_act[3], 64, nb, st)
+                      : launch_conv<80, 80, false, 8, 5>(d->d_act[2], d->d_wconv[3], d->d_bconv[3], d->d_act[3], 64, 1, nb, st);
+        if (rc) return rc;
     }
     {
         ProfSpan ps(d, st, 4, nb);
-        if ((rc = launch_conv<80, 80, true, 8, 5>(d->d_act[3], d->d_wconv[4], d->d_bconv[4], act4_out, 64,
-                                                               1, nb, st))) return rc;
+        rc = d->arith ? launch_conv_b3<80, true>(d->d_act[3], d->d_wb3[4], d->d_bconv[4], act4_out, 64, nb, st)
+                      : launch_conv<80, 80, true, 8, 5>(d->d_act[3], d->d_wconv[4], d->d_bconv[4], act4_out, 64, 1, nb, st);
+        if (rc) return rc;
     }
     return AXT_OK;
 }
@@ -1039,13 +1305,15 @@ int run_back(axt_detector *d, int nb, float *d_yolo, hipStream_t st)
     int rc;
     {
         ProfSpan ps(d, st, 5, nb);
-        if ((rc = launch_conv<80, 80, false, 8, 5>(d->d_act[4], d->d_wconv[5], d->d_bconv[5], d->d_act[5],
-                                                                32, 1, nb, st))) return rc;
+        rc = d->arith ? launch_conv_b3<80, false>(d->d_act[4], d->d_wb3[5], d->d_bconv[5], d->d_act[5], 32, nb, st)
+                      : launch_conv<80, 80, false, 8, 5>(d->d_act[4], d->d_wconv[5], d->d_bconv[5], d->d_act[5], 32, 1, nb, st);
+        if (rc) return rc;
     }
     {
         ProfSpan ps(d, st, 6, nb);
-        if ((rc = launch_conv<80, 80, true, 8, 5>(d->d_act[5], d->d_wconv[6], d->d_bconv[6], d->d_act[6],
-                                                               32, 1, nb, st))) return rc;
+        rc = d->arith ? launch_conv_b3<80, true>(d->d_act[5], d->d_wb3[6], d->d_bconv[6], d->d_act[6], 32, nb, st)
+                      : launch_conv<80, 80, true, 8, 5>(d->d_act[5], d->d_wconv[6], d->d_bconv[6], d->d_act[6], 32, 1, nb, st);
+        if (rc) return rc;
     }
     {
         ProfSpan ps(d, st, 7, nb);
@@ -1128,7 +1396,7 @@ int axt_detector_create(const float *const *h_tensors, int n_tensors, int max_ba
     std::vector<float> wp, bp;
     for (int li = 0; li < 8 && !rc; ++li) {
         const float *const *t = h_tensors + li * 6;
-        pack_conv(li, t[0], t[1], t[2], t[3], t[4], t[5], wp, bp);
+        pack_conv(li, t[0], t[1], t[2], t[3], t[4], t[5], wp, bp, (li >= 2 && li <= 6) ? &d->h_wfold[li] : nullptr);
         if ((rc = dev_alloc(d, &d->d_wconv[li], wp.size()))) break;
         if ((rc = dev_alloc(d, &d->d_bconv[li], bp.size()))) break;
         if (hipMemcpy(d->d_wconv[li], wp.data(), wp.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
@@ -1172,10 +1440,27 @@ int axt_detector_create(const float *const *h_tensors, int n_tensors, int max_ba
     return AXT_OK;
 }
 
+int axt_detector_set_arith(axt_detector *d, int mode)
+{
+    AXT_REQUIRE(d != nullptr && (mode == 0 || mode == 1), "axt_detector_set_arith: mode must be 0 (f32) or 1 (bf16x3)");
+    if (mode == 1 && !d->d_wb3[2]) {
+        std::vector<uint16_t> pk;
+        for (int li = 2; li <= 6; ++li) {
+            pack_bf16x3(kConv[li].cin, d->h_wfold[li], pk);
+            const int rc = dev_alloc(d, &d->d_wb3[li], pk.size() / 2);
+            if (rc) return rc;
+            AXT_CHECK_HIP(hipMemcpy(d->d_wb3[li], pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
+        }
+    }
+    d->arith = mode;
+    return AXT_OK;
+}
+
 void axt_detector_destroy(axt_detector *d)
 {
     if (!d) return;
     for (int i = 0; i < 8; ++i) {
+        (void)hipFree(d->d_wb3[i]);
         (void)hipFree(d->d_wconv[i]);
         (void)hipFree(d->d_bconv[i]);
         (void)hipFree(d->d_act[i]);

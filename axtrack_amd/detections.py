@@ -96,6 +96,8 @@ class AxonDetections(object):
         self.tile_yx = self.dataset.tile_yx
         if not self.tile_yx:
             raise ValueError('the timelapse is empty (no tile has a non-zero pixel)')
+        if hasattr(self.model, 'set_arith'):
+            self.model.set_arith(self.P.get('CNN_ARITH', 'f32'))       # read at inference time, like every parameter
         self._yolo = self.model.detect_frames(frames, self.tile_yx, 0, self.dataset.sizet)
         thr = float(np.float32(self.all_conf_thrs.min()))
         self.d_conf, self.d_x, self.d_y, self.d_count = hp.decode_stitch_nms(

@@ -15,6 +15,8 @@ DEPLOYED = dict(
     MCF_ENTRY_EXIT_COST=2, MCF_EDGE_COST_THR=0.7,
     LOG_CORRECT=True, STANDARDIZE=('zscore', None), STANDARDIZE_FRAMEWISE=False, USE_SPARSE=False,
     CLIP_LOWERLIM=55 / 2 ** 16, OFFSET=None, PAD=[0, 300, 0, 300],
+    # build-side switches (not in the reference's params.pkl): see INTEGRATION.md
+    CNN_ARITH='f32',
 )
 # ('zscore', (var_scalar, mean_scalar)) as unpickled from deployed_model/train_stnd_scaler.pkl (interface.py:66-67)
 DEPLOYED_STND_SCALER = ('zscore', (0.015176106, 0.009456525))

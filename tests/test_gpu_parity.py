@@ -1339,3 +1339,55 @@ def test_prepare_input_data_pad_mask_per_frame_and_dataset_cache(weights, tmp_pa
     _assert_dets_equal_oracle(ad, refi['dets'])
     assert tracks_from_next(np.zeros(len(ad._track_flat)), ad._track_flat, ad._offs) == refi['trajs']
     assert ad.mcf_total_cost == refi['total_cost']
+
+
+# ----------------------------------------------------------------------------------------- opt-in arithmetic (CNN_ARITH)
+def test_cnn_bf16x3_arithmetic_against_oracle_and_f32_path(golden, weights):
+    """parameters['CNN_ARITH'] = 'bf16x3': the stride-1 conv blocks with 80 output channels on the bf16 matrix pipe (three
+    bf16 terms per f32 operand, six partial products, f32 accumulation). Same tolerance as the f32 kernels against the
+    reference's golden grids and the oracle's f32 forward pass (edge inputs: zero padding of every layer, hot corner
+    pixels, a frame width that is not a multiple of 4), and within 2e-5 of the f32 kernels themselves; switching back
+    restores the f32 results bit for bit."""
+    import axtrack_amd
+    det = axtrack_amd.Detector(weights, max_batch=24)
+    g = golden('cnn_512')
+    frames = dev(synth.synth_frames(int(g['T_all']), 512, 512, seed=int(g['frames_seed'])))
+    y32 = det.detect_frames(frames, [(0, 0)]).cpu().numpy()
+    det.set_arith('bf16x3')
+    yb = det.detect_frames(frames, [(0, 0)]).cpu().numpy()
+    np.testing.assert_allclose(yb[:, 0], g['yolo'], atol=CNN_ATOL, rtol=CNN_RTOL)
+    assert np.abs(yb[:, 0] - g['yolo']).max() < 5e-5
+    assert not np.array_equal(yb, y32) and np.abs(yb - y32).max() < 2e-5
+    X = np.zeros((4, 5, 512, 512), np.float32)
+    X[1] = 1.0
+    for c, (yy, xx) in enumerate([(0, 0), (0, 511), (511, 0), (511, 511), (255, 256)]):
+        X[2, c, yy, xx] = 50.0
+    X[3] = synth.synth_frames(5, 512, 512, seed=9) * 3
+    np.testing.assert_allclose(det.detect_axons(dev(X)).cpu().numpy(), orc.cnn_forward(weights, X), atol=CNN_ATOL, rtol=CNN_RTOL)
+    fr = synth.synth_frames(6, 600, 1022, seed=3)                          # ragged, width not a multiple of 4
+    keep = hp.tile_occupancy(dev(fr))
+    y = det.detect_frames(dev(fr), keep).cpu().numpy()
+    for t in range(2):
+        np.testing.assert_allclose(y[t], orc.cnn_forward(weights, orc.frame_tile_stack(fr, t, keep)), atol=CNN_ATOL, rtol=CNN_RTOL)
+    det.set_arith('f32')
+    assert np.array_equal(det.detect_frames(frames, [(0, 0)]).cpu().numpy(), y32)
+    with pytest.raises(ValueError):
+        det.set_arith('fp8')
+
+
+def test_inference_with_bf16x3_parameter(weights):
+    """The parameter is read at inference time (callers edit the dict between the steps, examples/test.py:19): the whole
+    path with CNN_ARITH='bf16x3' -- detections and trajectories equal the oracle's given the grids the detector produced,
+    and the grids are within tolerance of the oracle's forward pass."""
+    import axtrack_amd
+    frames = synth.synth_frames(12, 512, 512, seed=19)
+    model = axtrack_amd.Detector(weights, max_batch=8)
+    P = dict(params.load_parameters(), CNN_ARITH='bf16x3', MCF_MIN_FLOW=1)
+    ad = axtrack_amd.inference(axtrack_amd.Timelapse(frames, name='synth'), model, None, P, None, None, None)
+    assert model.arith == 'bf16x3'
+    yolo = ad._yolo.cpu().numpy()
+    for t in (0, 7):
+        np.testing.assert_allclose(yolo[t], orc.cnn_forward(weights, orc.frame_tile_stack(frames, t, ad.tile_yx)), atol=CNN_ATOL, rtol=CNN_RTOL)
+    ref = orc.inference(frames, weights, P=dict(orc.DEFAULTS, MCF_MIN_FLOW=1), yolo=list(yolo))
+    _assert_dets_equal_oracle(ad, ref['dets'])
+    assert tracks_from_next(np.zeros(len(ad._track_flat)), ad._track_flat, ad._offs) == ref['trajs']
