@@ -288,32 +288,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(
 //   Every f32 operand is split exactly into three bf16 terms, x = hi + mid + lo (8 + 8 + 8 mantissa bits), and a product
 //   x*w is taken as the six partial products of weight >= 2^-16: hi*hi, hi*mid, mid*hi, hi*lo, mid*mid, lo*hi. Each
 //   bf16 x bf16 product is exact in f32 and the accumulation is f32, so one product carries a relative error of about
-//   3 * 2^-24 -- the size of an f32 rounding -- at 6/16 of the f32 pipe's cycles per multiply-add
-//   (v_mfma_f32_16x16x32_bf16: 16 x 16 outputs x 32 k in 16 cycles against 16 x 16 x 4 in 32).
-//   Same tiling as conv3x3_mfma: 16 x 16 output pixels per workgroup, wave w owns rows 4w..4w+3 and all 80 channels
-//   (4 x 5 accumulator tiles), one wave per SIMD with the whole register file (512): the next chunk's global loads
-//   (24 + 76 registers) wait in registers behind the MFMAs.
-//   K runs in chunks of 16 input channels. One MFMA k-step (32 k) = four "pairs" of (tap, 8-channel half): lane (p, q)
-//   holds pixel p's 8 channels of pair q as ONE 16-byte LDS read. A chunk has 9 taps x 2 halves = 18 pairs = 4.5
-//   k-steps, padded to 5 with zero weights (10 %).
-//   LDS: patch [plane hi|mid|lo][half][18 rows][18 cols][8 ch] bf16, halves padded to a multiple of 256 B so that the two
-//   halves a 16-lane read group touches fall on disjoint banks; weights [k-step][plane][q][80 n][8 k] bf16, copied
-//   verbatim from the packed image (axt_pack_bf16x3). The f32 -> 3 x bf16 split of the activations happens on the way
-//   from the prefetch registers into LDS (v_cvt_pk_bf16_f32, round to nearest even; the residuals are exact in f32).
+//   3 * 2^-24 -- the size of an f32 rounding -- at 6/16 of the f32 pipe's cycles per multiply-add.
+//   Shape and occupancy (profiles/micro/mfma_bf16_shapes.hip, random operands): v_mfma_f32_16x16x32_bf16 fits 80 = 5 x 16
+//   channels exactly, but ONE wave per SIMD issues it only every 27.5 cycles (1.41 PFLOP/s); two waves per SIMD reach
+//   17.7 cycles (1.84 PFLOP/s at the 2.0 GHz the chip holds under that load). The 32x32x16 shape issues every 33 cycles
+//   from one wave (1.85 PFLOP/s) but pads 80 channels to 96 and pulls the clock to 1.86 GHz for the whole kernel: built
+//   and measured slower than this one. Hence 8 waves per workgroup, one workgroup per CU.
+//   Tile: 32 x 16 output pixels per workgroup, wave w owns rows 4w..4w+3 and all 80 channels (4 x 5 accumulator tiles of
+//   16 x 16). K runs in chunks of 16 input channels. One MFMA k-step (32 k) = four "pairs" of (tap, 8-channel half):
+//   lane (p, q) holds pixel p's 8 channels of pair q as ONE 16-byte LDS read. A chunk has 9 taps x 2 halves = 18 pairs
+//   = 4.5 k-steps, padded to 5 with zero weights (10 %).
+//   LDS (134 KB): patch [plane hi|mid|lo][half][34 rows][18 cols][8 ch] bf16, halves padded to a multiple of 256 B so that
+//   the two halves a 16-lane read group touches fall on disjoint banks; weights [k-step][plane][q][80 n][8 k] bf16, copied
+//   verbatim from the packed image (pack_bf16x3). The next chunk's global loads (24 + 40 registers) wait in registers
+//   behind the MFMAs; the f32 -> 3 x bf16 split of the activations happens on the way from those registers into LDS
+//   (v_cvt_pk_bf16_f32, round to nearest even; the residuals are exact in f32).
 //   Input and output stay f32 NCHW, so the layer is interchangeable with conv3x3_mfma block by block.
 // ------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 struct GeoB3 {
-    static constexpr int CCH = 16, MT = 4, NT = 5, PH = 18, PW = 18, KS = 5;
-    static constexpr int HALF_B = ((PH * PW * 16 + 255) / 256) * 256;      // 5376 bytes
+    static constexpr int CCH = 16, MT = 4, NT = 5, TH = 32, TW = 16, PH = TH + 2, PW = TW + 2, KS = 5, WAVES = 8;
+    static constexpr int HALF_B = ((PH * PW * 16 + 255) / 256) * 256;      // 9984 bytes
     static constexpr int PLANE_B = 2 * HALF_B;
-    static constexpr int PATCH_B = 3 * PLANE_B;                             // 32256
+    static constexpr int PATCH_B = 3 * PLANE_B;                             // 59904
     static constexpr int WQ_B = NT * 16 * 16;                               // one (k-step, plane, q) block: 80 n x 16 B
     static constexpr int WSTEP_B = 3 * 4 * WQ_B;
     static constexpr int WCHUNK_B = KS * WSTEP_B;                           // 76800
-    static constexpr int LDS_B = PATCH_B + WCHUNK_B;                        // 109056
+    static constexpr int LDS_B = PATCH_B + WCHUNK_B;                        // 136704
     static constexpr int DUMMY = PH * PW * 16;                              // first padding byte of half 0: never read
 };
 
@@ -335,7 +338,7 @@ __device__ __forceinline__ void split_bf16x3(const float (&x)[8], u32x4 &H, u32x
 }
 
 template <int CIN, bool POOL>
-__global__ __launch_bounds__(256, 1) void conv3x3_bf16x3(
+__global__ __launch_bounds__(512, 1) void conv3x3_bf16x3(
     const float *__restrict__ in,       // activations [B,CIN,Hin,Hin] f32
     const unsigned *__restrict__ wpk,   // packed weights: per chunk the LDS image [KS][3][4][80][8] bf16
     const float *__restrict__ bias,     // folded bias [80]
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16x3(
     int Hin, int B)
 {
     using G = GeoB3;
-    constexpr int COUT = 80, MT = G::MT, NT = G::NT, PH = G::PH, PW = G::PW;
+    constexpr int COUT = 80, MT = G::MT, NT = G::NT, PH = G::PH, PW = G::PW, NTHR = 64 * G::WAVES;
     constexpr int NCHUNK = (CIN + G::CCH - 1) / G::CCH;
 
     extern __shared__ __attribute__((aligned(256))) unsigned char smem_b[];
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16x3(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int p = lane & 15, q = lane >> 4;
-    const int tiles_x = Hin / 16, ntile = tiles_x * tiles_x;
+    const int tiles_x = Hin / G::TW, ntile = tiles_x * (Hin / G::TH);
     int w;
     {
         const int nwg = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -360,19 +363,19 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16x3(
         w = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + slot;
     }
     const int tile = w % ntile, b = w / ntile;
-    const int y0 = (tile / tiles_x) * 16, x0 = (tile % tiles_x) * 16;
+    const int y0 = (tile / tiles_x) * G::TH, x0 = (tile % tiles_x) * G::TW;
     const int cstride = Hin * Hin;
     const int Hout = POOL ? Hin / 2 : Hin;
 
-    // staging plan of the patch: item e = tid + k*256 is (half h, row r, col): 8 channels of one pixel. The global side
+    // staging plan of the patch: item e = tid + k*512 is (half h, row r, col): 8 channels of one pixel. The global side
     // is eight buffer loads (one per channel, coalesced along the row); pixels outside the image carry an
     // out-of-range offset and channels beyond CIN fall behind the descriptor's range: both read as the zero padding.
-    constexpr int NITEM = 2 * PH * PW;                 // 648
-    constexpr int NPE = (NITEM + 255) / 256;           // 3
+    constexpr int NITEM = 2 * PH * PW;                       // 1224
+    constexpr int NPE = (NITEM + NTHR - 1) / NTHR;           // 3
     unsigned gofs[NPE], lofs[NPE];
 #pragma unroll
     for (int k = 0; k < NPE; ++k) {
-        const int e = tid + k * 256;
+        const int e = tid + k * NTHR;
         const int h = e / (PH * PW), rem = e - h * (PH * PW);
         const int r = rem / PW, col = rem - r * PW;
         const int gy = y0 - 1 + r, gx = x0 - 1 + col;
@@ -381,8 +384,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16x3(
         gofs[k] = ok ? (unsigned)((8 * h * cstride + gy * Hin + gx) * 4) : kOobOffset;
         lofs[k] = in_patch ? (unsigned)(h * G::HALF_B + (r * PW + col) * 16) : (unsigned)G::DUMMY;
     }
-    constexpr int NW16 = G::WCHUNK_B / 16;             // 4800 16-byte elements per chunk
-    constexpr int NWE = (NW16 + 255) / 256;            // 19
+    constexpr int NW16 = G::WCHUNK_B / 16;                   // 4800 16-byte elements per chunk
+    constexpr int NWE = (NW16 + NTHR - 1) / NTHR;            // 10
     float pv[NPE][8];
     u32x4 wv[NWE];
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -401,7 +404,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16x3(
         const unsigned wbase = (unsigned)(chunk * G::WCHUNK_B);
 #pragma unroll
         for (int k = 0; k < NWE; ++k) {
-            const int e = tid + k * 256;
+            const int e = tid + k * NTHR;
             wv[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, e < NW16 ? (int)(wbase + e * 16) : (int)kOobOffset, 0, 0));
         }
     };
@@ -416,13 +419,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16x3(
         }
 #pragma unroll
         for (int k = 0; k < NWE; ++k) {
-            const int e = tid + k * 256;
+            const int e = tid + k * NTHR;
             if (k + 1 < NWE || e < NW16) *reinterpret_cast<u32x4 *>(wl + e * 16) = wv[k];
         }
     };
-    float bias_v[NT];
-    load_bias<COUT, NT>(bias, 0, p, bias_v);
-
     const unsigned a_lane = (unsigned)((q & 1) * G::HALF_B + ((wave * MT) * PW + p) * 16);
     const unsigned b_lane = (unsigned)(q * G::WQ_B + p * 16);
 
@@ -438,42 +438,73 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16x3(
         store_chunk();
         __syncthreads();
         if (chunk + 1 < NCHUNK) load_chunk(chunk + 1);
-#pragma unroll
-        for (int s = 0; s < G::KS; ++s) {
+        // Operands run ahead of the MFMAs in register double buffers, so that no block starts with a wait: a k-step is done
+        // in two halves of two rows each -- block (s, half, n) = 2 rows x 6 partial products = 12 MFMAs; the three weight
+        // fragments of the next block are fetched before them, the six pixel fragments of the next half during block
+        // (s, half, 1) -- and the group barriers pin that interleave. (With all twelve pixel fragments of a k-step loaded at
+        // its head, the two waves of a SIMD, which leave every barrier in step, stalled on them together: matrix pipe
+        // busy 62 % of the time.)
+        bf16x8 A[2][3][2], Bv[2][3];
+        auto load_a = [&](int hidx, int buf) {
             // pairs 4s + q: tap (4s + q) / 2 (the padding pairs of the last step re-read tap 8: finite values, zero weights)
             constexpr int kLast = 8;
+            const int s = hidx >> 1, h = hidx & 1;
             const int tap_a = 2 * s < kLast ? 2 * s : kLast, tap_b = 2 * s + 1 < kLast ? 2 * s + 1 : kLast;
             const unsigned off_a = (unsigned)(((tap_a / 3) * PW + tap_a % 3) * 16);
             const unsigned off_b = (unsigned)(((tap_b / 3) * PW + tap_b % 3) * 16);
-            const unsigned toff = a_lane + ((q >> 1) ? off_b : off_a);
-            bf16x8 A[3][MT];
+            const unsigned toff = a_lane + ((q >> 1) ? off_b : off_a) + (unsigned)(2 * h * PW * 16);
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    A[pl][m] = *reinterpret_cast<const bf16x8 *>(patch + pl * G::PLANE_B + toff + m * PW * 16);
+                for (int m = 0; m < 2; ++m)
+                    A[buf][pl][m] = *reinterpret_cast<const bf16x8 *>(patch + pl * G::PLANE_B + toff + m * PW * 16);
+        };
+        auto load_b = [&](int s, int n, int buf) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                Bv[buf][pl] = *reinterpret_cast<const bf16x8 *>(wl + (s * 3 + pl) * 4 * G::WQ_B + b_lane + n * 256);
+        };
+        load_a(0, 0);
+        load_b(0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
+        constexpr int NBLK = G::KS * 2 * NT;
+#pragma unroll
+        for (int hidx = 0; hidx < 2 * G::KS; ++hidx) {
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                bf16x8 Bv[3];
+                const int blk = hidx * NT + n, cur = blk & 1, ab = hidx & 1, h = hidx & 1;
+                const bool more = blk + 1 < NBLK;
+                const bool next_a = n == 1 && hidx + 1 < 2 * G::KS;
+                if (more) load_b((n + 1 < NT ? hidx : hidx + 1) >> 1, n + 1 < NT ? n + 1 : 0, cur ^ 1);
+                if (next_a) load_a(hidx + 1, ab ^ 1);
+                // the six partial products, small terms first
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    Bv[pl] = *reinterpret_cast<const bf16x8 *>(wl + (s * 3 + pl) * 4 * G::WQ_B + b_lane + n * 256);
-                // the six partial products, small terms first; consecutive MFMAs go to different accumulators
+                for (int m = 0; m < 2; ++m) acc[2 * h + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ab][0][m], Bv[cur][2], acc[2 * h + m][n], 0, 0, 0);
 #pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0][m], Bv[2], acc[m][n], 0, 0, 0);
+                for (int m = 0; m < 2; ++m) acc[2 * h + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ab][2][m], Bv[cur][0], acc[2 * h + m][n], 0, 0, 0);
 #pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[2][m], Bv[0], acc[m][n], 0, 0, 0);
+                for (int m = 0; m < 2; ++m) acc[2 * h + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ab][1][m], Bv[cur][1], acc[2 * h + m][n], 0, 0, 0);
 #pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1][m], Bv[1], acc[m][n], 0, 0, 0);
+                for (int m = 0; m < 2; ++m) acc[2 * h + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ab][0][m], Bv[cur][1], acc[2 * h + m][n], 0, 0, 0);
 #pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0][m], Bv[1], acc[m][n], 0, 0, 0);
+                for (int m = 0; m < 2; ++m) acc[2 * h + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ab][1][m], Bv[cur][0], acc[2 * h + m][n], 0, 0, 0);
 #pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1][m], Bv[0], acc[m][n], 0, 0, 0);
+                for (int m = 0; m < 2; ++m) acc[2 * h + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ab][0][m], Bv[cur][0], acc[2 * h + m][n], 0, 0, 0);
+                if (more) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                if (next_a) {
 #pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0][m], Bv[0], acc[m][n], 0, 0, 0);
+                    for (int g = 0; g < 6; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+                }
             }
         }
     }
+    float bias_v[NT];                     // loaded here: nothing is in flight any more, and five registers fewer live in the loop
+    load_bias<COUT, NT>(bias, 0, p, bias_v);
     conv_epilogue<COUT, POOL, MT, NT>(acc, bias_v, out, b, 0, y0, x0, wave, p, q, Hout, Hout);
 }
 
@@ -1136,10 +1167,10 @@ int launch_conv_b3(const float *in, const unsigned *w, const float *bias, float 
         AXT_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GeoB3::LDS_B));
         attr_set = true;
     }
-    AXT_REQUIRE(Hin % 16 == 0 && w != nullptr, "conv (bf16x3): map size %d not a multiple of the 16x16 tile, or weights not packed", Hin);
+    AXT_REQUIRE(Hin % GeoB3::TH == 0 && w != nullptr, "conv (bf16x3): map size %d not a multiple of the 32x16 tile, or weights not packed", Hin);
     AXT_REQUIRE((double)CIN * Hin * Hin * 4 < 2.0e9, "conv (bf16x3): map too large");
-    const int nwork = (Hin / 16) * (Hin / 16) * B;
-    hipLaunchKernelGGL(kern, dim3(nwork), dim3(256), GeoB3::LDS_B, st, in, w, bias, out, Hin, B);
+    const int nwork = (Hin / GeoB3::TH) * (Hin / GeoB3::TW) * B;
+    hipLaunchKernelGGL(kern, dim3(nwork), dim3(64 * GeoB3::WAVES), GeoB3::LDS_B, st, in, w, bias, out, Hin, B);
     AXT_LAUNCH_CHECK();
     return AXT_OK;
 }
