@@ -199,7 +199,9 @@ int axt_path_cost_masked(const int32_t *d_xa, const int32_t *d_ya, int na, const
 //   * level-0 targets (T == S, or T on the mask in a component S touches): BFS over on-mask cells, depth-limited to
 //     dmax-1 moves; not reached within that depth => the optimum is longer than dmax cells => no arc;
 //   * other targets (off-mask, or in a component S does not touch) close enough that a path of <= dmax cells could
-//     exist: marked for the exact general search above (rare in real data: detections sit on the mask).
+//     exist: with the component fields (axt_grid::d_off / d_tight) they are served by the same search over "tight"
+//     steps -- sources on the mask: one front; sources off it: two fronts (see mask_bfs_kernel) -- and only without
+//     the fields (more than 64 components), or where two components tie, marked for the searches further down.
 // The BFS is bit-parallel: the (2R+1)^2 window around S lives in LDS as three bitmaps (reached A/B, mask M); one BFS
 // step is a 4-/8-neighbour dilation of whole 32-cell words, AND-ed with the mask. One workgroup per source serves
 // the targets of BOTH following frames (gaps 1 and 2).
@@ -232,21 +234,140 @@ __device__ __forceinline__ unsigned int dil_h(const unsigned int *row, int w)
     return c | (c << 1) | (l >> 31) | (c >> 1) | (r << 31);
 }
 
-// Dtmp[((t*cap + i) * max_gap + g-1) * cap + j]: path length (cells) if <= dmax[g-1], 0 = no arc, -1 = needs exact search
 constexpr int BFS_THREADS = 1024;      // one workgroup per CU (LDS-bound): many waves hide the LDS latency of the sweeps
 
+struct BfsGeo { int wy0, wx0, H, W, Ww, depth, sr, sc, n_targets; };
+
+// Breadth-first search over the tight steps of one component's field (bit rows tg, axt_grid::d_tight), bit-parallel on
+// the window bitmaps in LDS. Every thread owns the words e = tid + k * 1024 of the window for the whole search and
+// keeps their tight-step rows (one word per direction) in registers: a move then costs LDS reads and one barrier, no
+// global memory (with the rows fetched from L2 inside every move a move took ~4 us: several dependent L2 round trips).
+//   off == false: source on the mask; front c0/c1 (ping-pong), seeded by the caller in c0.
+//   off == true : source off the mask; the all-off front in c0/c1 (dilation over off-mask cells, seeded with the source)
+//                 and, from move best_a + 1 on, the front over the mask in v0/v1 (tight steps of component best_comp,
+//                 seeded with the mask cells next to the all-off front). A target is settled by the all-off front at
+//                 move s iff s <= tkv (see the kernel), else by the other front.
+// One barrier per move: per-move flags in LDS (three in rotation) carry "some word changed" and "some target is still
+// open" (as of the previous move's checks), so the checks of move s run beside the dilation of move s + 1.
+template <int NDIR>
+__device__ __forceinline__ void bfs_owned(bool off, unsigned int *c0, unsigned int *c1, unsigned int *v0, unsigned int *v1,
+                                          const unsigned int *__restrict__ tg, const unsigned int *__restrict__ bits,
+                                          const BfsGeo &G, int *tpos, short *tres, const short *tkv, int (*s_step)[2],
+                                          int best_comp, int best_a, int tid)
+{
+    constexpr int NWORDS = BFS_WH * BFS_WW;
+    constexpr int KW = (NWORDS + BFS_THREADS - 1) / BFS_THREADS;           // 9
+    constexpr int oy8[8] = {-1, 1, 0, 0, -1, -1, 1, 1}, ox8[8] = {0, 0, -1, 1, -1, 1, -1, 1};
+    unsigned int tw[KW][NDIR], mbk[KW], okk[KW];
+    const long dstride = (long)G.H * G.Ww;
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        const int e = tid + k * BFS_THREADS;
+        const int r = e / BFS_WW, w = e - r * BFS_WW;
+        const int gy = G.wy0 + r, gw = (G.wx0 >> 5) + w;
+        const bool ing = e < NWORDS && gy >= 0 && gy < G.H && gw >= 0 && gw < G.Ww;
+#pragma unroll
+        for (int d = 0; d < NDIR; ++d) tw[k][d] = (ing && tg) ? tg[d * dstride + (long)gy * G.Ww + gw] : 0u;
+        const unsigned int mb = (ing && off) ? bits[(long)gy * G.Ww + gw] : 0u;
+        const unsigned int valid = !ing ? 0u : (gw == G.Ww - 1 && (G.W & 31)) ? ((1u << (G.W & 31)) - 1u) : 0xffffffffu;
+        mbk[k] = mb;
+        okk[k] = ~mb & valid;
+    }
+    int my_open = 0;
+    for (int e = tid; e < G.n_targets; e += BFS_THREADS) my_open |= (tpos[e] >= 0);
+    unsigned int *fc = off ? v0 : c0, *fn = off ? v1 : c1;          // the front over tight steps
+    unsigned int *oc = c0, *on = c1;                                 // (off) the all-off front
+    for (int s = 1; s <= G.depth; ++s) {
+        // after s moves only the cells within s of the source can be set: rows sr-s..sr+s, words of columns sc-s..sc+s
+        const int rlo = max(0, G.sr - s), rhi = min(BFS_WH - 1, G.sr + s);
+        const int wlo = max(0, (G.sc - s) >> 5), whi = min(BFS_WW - 1, (G.sc + s) >> 5);
+        int changed = 0;
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+            const int e = tid + k * BFS_THREADS;
+            const int r = e / BFS_WW, w = e - r * BFS_WW;
+            if (e >= NWORDS || r < rlo || r > rhi || w < wlo || w > whi) continue;
+            unsigned int d_off_front = 0u;
+            if (off) {
+                const unsigned int *row = oc + r * BFS_WW;
+                unsigned int d = dil_h(row, w);
+                if (NDIR == 8) {
+                    if (r > 0) d |= dil_h(row - BFS_WW, w);
+                    if (r + 1 < BFS_WH) d |= dil_h(row + BFS_WW, w);
+                } else {
+                    if (r > 0) d |= row[w - BFS_WW];
+                    if (r + 1 < BFS_WH) d |= row[w + BFS_WW];
+                }
+                const unsigned int vo = row[w] | (d & okk[k]);
+                on[e] = vo;
+                changed |= (vo != row[w]);
+                d_off_front = d;
+            }
+            const unsigned int old = fc[e];
+            unsigned int vv = old;
+            if (off && s == best_a + 1) {
+                if (best_comp > 0) vv |= d_off_front & mbk[k];               // the step from the all-off front onto the mask
+            } else if (!off || (best_comp > 0 && s > best_a + 1)) {
+#pragma unroll
+                for (int d = 0; d < NDIR; ++d) {
+                    const int rp = r + oy8[d];
+                    if (rp < 0 || rp >= BFS_WH) continue;
+                    const unsigned int *prow = fc + rp * BFS_WW;
+                    const unsigned int p0 = prow[w];
+                    unsigned int from;
+                    if (ox8[d] < 0) from = (p0 << 1) | (w > 0 ? prow[w - 1] >> 31 : 0u);
+                    else if (ox8[d] > 0) from = (p0 >> 1) | (w + 1 < BFS_WW ? prow[w + 1] << 31 : 0u);
+                    else from = p0;
+                    vv |= from & tw[k][d];
+                }
+            }
+            fn[e] = vv;
+            changed |= (vv != old);
+        }
+        if (changed) s_step[s % 3][0] = 1;
+        if (my_open) s_step[s % 3][1] = 1;
+        __syncthreads();
+        const int both = s_step[s % 3][0] | (s_step[s % 3][1] << 1);
+        if (tid == 0) s_step[(s + 2) % 3][0] = s_step[(s + 2) % 3][1] = 0;      // for the move after the next one
+        if (!(both & 2)) break;                                        // every target was settled by the previous move
+        my_open = 0;
+        for (int e = tid; e < G.n_targets; e += BFS_THREADS) {
+            const int pos = tpos[e];
+            if (pos < 0) continue;
+            const int r = pos / (BFS_WW * 32), c = pos - r * (BFS_WW * 32);
+            const bool by_off = off && (on[r * BFS_WW + (c >> 5)] >> (c & 31) & 1u) && s <= (int)tkv[e];
+            const bool by_front = fn[r * BFS_WW + (c >> 5)] >> (c & 31) & 1u;
+            if (by_off || by_front) {
+                tres[e] = (short)(s + 1);
+                tpos[e] = -1;
+            } else {
+                my_open = 1;
+            }
+        }
+        unsigned int *sw = fc; fc = fn; fn = sw;
+        sw = oc; oc = on; on = sw;
+        if (!(both & 1)) break;                                        // no front moved
+    }
+}
+
+// Dtmp[((t*cap + i) * max_gap + g-1) * cap + j]: path length (cells) if <= dmax[g-1], 0 = no arc, -1 = needs exact search
 __global__ __launch_bounds__(BFS_THREADS) void mask_bfs_kernel(
     const int *__restrict__ x, const int *__restrict__ y, const int *__restrict__ count, const int *__restrict__ src_count,
     int n_frames, int cap, const unsigned int *__restrict__ bits, const int *__restrict__ label, int H, int W, int Ww,
     int conn8, int max_dist, int max_gap, const int *__restrict__ dmax, short *__restrict__ Dtmp,
-    const unsigned int *__restrict__ tight)
+    const unsigned int *__restrict__ tight, const unsigned char *__restrict__ off_field, int n_comp, int off_mode_ok)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned int bsm[];
     unsigned int *A = bsm, *Bm = A + BFS_WH * BFS_WW, *M = Bm + BFS_WH * BFS_WW;
-    int *tpos = reinterpret_cast<int *>(M + BFS_WH * BFS_WW);      // [max_gap*cap] window bit position or -1
+    // a fourth bitmap only when the launch provides it (off_mode_ok): sources off the mask run two wavefronts
+    unsigned int *V2 = M + BFS_WH * BFS_WW;
+    int *tpos = reinterpret_cast<int *>(M + (off_mode_ok ? 2 : 1) * BFS_WH * BFS_WW);      // [max_gap*cap] window bit position or -1
     short *tres = reinterpret_cast<short *>(tpos + max_gap * cap); // [max_gap*cap]
+    short *tkv = tres + max_gap * cap;                             // [max_gap*cap] (off_mode_ok) off-cell count of the best path over the mask
     __shared__ int s_labels[8];
     __shared__ int n_slab, n_open;
+    __shared__ int s_best_comp, s_best_a;
+    __shared__ int s_step[3][2];          // per move (three in rotation): [0] some word changed, [1] some target is still open
 
     const int t = blockIdx.y, i = blockIdx.x, tid = threadIdx.x;
     if (i >= min(src_count[t], cap)) return;
@@ -265,7 +386,31 @@ __global__ __launch_bounds__(BFS_THREADS) void mask_bfs_kernel(
     const int ls_src = s_in ? label[(long)sy * W + sx] : 0;
     const bool tight_mode = tight != nullptr && ls_src > 0;
     const int ndir = conn8 ? 8 : 4;
-    const unsigned int *tg = tight_mode ? tight + (long)(ls_src - 1) * ndir * H * Ww : nullptr;
+    // A source OFF the mask (this round): the fewest off-mask cells of its paths are K(c) = min(P(c), min over
+    // components A of a_A + d_off[A][c]) -- P = all-off paths (as many moves as off-mask cells), a_A = d_off[A][S] - 1 =
+    // off-mask cells entered before the mask is first touched, in component A. Minimum-cost paths that touch the mask
+    // first in A are: an all-off walk of exactly a_A cells, one step onto A, then tight steps of A's field. So two
+    // wavefronts in the same loop: the all-off breadth-first search (dilation over off-mask cells), and from step
+    // a_A + 1 on the tight-step search of the component A with the smallest a_A, seeded with the mask cells next to the
+    // all-off front. A target is settled by the all-off front at step s iff s <= a_A + d_off[A][T] (an all-off path has
+    // the fewest moves of all paths with that many off-mask cells), else by the other front. Targets for which another
+    // component could do as well (a_B + d_off[B][T] <= a_A + d_off[A][T]) are left to the windowed search.
+    const bool off_mode = off_mode_ok && tight != nullptr && off_field != nullptr && s_in && ls_src == 0;
+    if (off_mode) {
+        if (tid == 0) {
+            int best = 0, ba = 0x7fffffff;
+            for (int a = 0; a < n_comp; ++a) {
+                const int v = off_field[((long)a * H + sy) * W + sx];
+                if (v < 255 && v - 1 < ba) { ba = v - 1; best = a + 1; }
+            }
+            s_best_comp = best;
+            s_best_a = ba;
+        }
+        __syncthreads();
+    }
+    const int best_comp = off_mode ? s_best_comp : 0, best_a = off_mode ? s_best_a : 0;
+    const unsigned int *tg = tight_mode ? tight + (long)(ls_src - 1) * ndir * H * Ww
+                             : (off_mode && best_comp > 0) ? tight + (long)(best_comp - 1) * ndir * H * Ww : nullptr;
 
     // ---- source labels
     if (tid == 0) {
@@ -288,14 +433,16 @@ __global__ __launch_bounds__(BFS_THREADS) void mask_bfs_kernel(
         }
         n_slab = n;
         n_open = 0;
+        for (int k = 0; k < 3; ++k) s_step[k][0] = s_step[k][1] = 0;
     }
     // ---- window bitmaps
     for (int e = tid; e < BFS_WH * BFS_WW; e += BFS_THREADS) {
         const int r = e / BFS_WW, w = e - r * BFS_WW;
         const int gy = wy0 + r, gw = (wx0 >> 5) + w;
-        M[e] = (gy >= 0 && gy < H && gw >= 0 && gw < Ww) ? bits[(long)gy * Ww + gw] : 0u;
+        M[e] = (off_mode || !(gy >= 0 && gy < H && gw >= 0 && gw < Ww)) ? 0u : bits[(long)gy * Ww + gw];   // off mode: M is the second front
         A[e] = 0u;
         Bm[e] = 0u;
+        if (off_mode) V2[e] = 0u;
     }
     __syncthreads();
     // ---- targets of frames t+1 .. t+max_gap
@@ -311,7 +458,21 @@ __global__ __launch_bounds__(BFS_THREADS) void mask_bfs_kernel(
             const int lower = (conn8 ? (int)max(labs(dx), labs(dy)) : (int)(labs(dx) + labs(dy))) + 1;   // cells needed at least
             if (t_in && dx * dx + dy * dy < (long)max_dist * max_dist && lower <= lim) {
                 if (dx == 0 && dy == 0) res = 1;
-                else {
+                else if (off_mode) {
+                    int kv = 0x7fff;
+                    bool ambiguous = false;
+                    if (best_comp > 0) {
+                        const int ft = off_field[((long)(best_comp - 1) * H + ty) * W + tx];
+                        if (ft < 255) kv = best_a + ft;
+                        for (int a = 0; a < n_comp && !ambiguous; ++a) {
+                            if (a == best_comp - 1) continue;
+                            const int fs = off_field[((long)a * H + sy) * W + sx], fb = off_field[((long)a * H + ty) * W + tx];
+                            if (fs < 255 && fb < 255 && fs - 1 + fb <= kv) ambiguous = true;
+                        }
+                    }
+                    if (ambiguous) res = -1;                          // the windowed search decides
+                    else { pos = (ty - wy0) * (BFS_WW * 32) + (tx - wx0); atomicAdd(&n_open, 1); tkv[e] = (short)kv; }
+                } else {
                     const int lt = label[(long)ty * W + tx];
                     bool level0 = tight_mode;
                     for (int k = 0; k < n_slab; ++k) level0 |= (lt != 0 && s_labels[k] == lt);
@@ -326,14 +487,32 @@ __global__ __launch_bounds__(BFS_THREADS) void mask_bfs_kernel(
     if (tid == 0 && s_in) {
         const int e = (sy - wy0) * BFS_WW + ((sx - wx0) >> 5);
         A[e] |= 1u << ((sx - wx0) & 31);
-        M[e] |= 1u << ((sx - wx0) & 31);                              // the seed counts even off the mask
+        if (!off_mode) M[e] |= 1u << ((sx - wx0) & 31);               // the seed counts even off the mask
     }
     __syncthreads();
 
+    const int sr = BFS_R, sc = sx - wx0;                              // the source's window row / column
+    if (off_mode || tight_mode) {
+        // ---- searches over tight steps (source on the mask, or off it with the two fronts): every thread owns fixed words
+        // of the window and keeps their tight-step rows in registers
+        const BfsGeo geo{wy0, wx0, H, W, Ww, depth, sr, sc, max_gap * cap};
+        if (conn8) bfs_owned<8>(off_mode, A, Bm, M, V2, tg, bits, geo, tpos, tres, tkv, s_step, best_comp, best_a, tid);
+        else bfs_owned<4>(off_mode, A, Bm, M, V2, tg, bits, geo, tpos, tres, tkv, s_step, best_comp, best_a, tid);
+        __syncthreads();
+        for (int e = tid; e < max_gap * cap; e += BFS_THREADS) {
+            const int g = e / cap;
+            short r = tres[e];
+            if (r > 0 && r > dmax[g]) r = 0;
+            drow[e] = r;
+        }
+        return;
+    }
+
     // ---- breadth-first search, one dilation per move
     unsigned int *cur = A, *nxt = Bm;
-    const int sr = BFS_R, sc = sx - wx0;                              // the source's window row / column
-    for (int s = 1; s <= depth && n_open > 0; ++s) {
+    int my_open = 0;                                                   // (one barrier per move, as above)
+    for (int e = tid; e < max_gap * cap; e += BFS_THREADS) my_open |= (tpos[e] >= 0);
+    for (int s = 1; s <= depth; ++s) {
         // after s moves only the cells within s of the source can be set: rows sr-s..sr+s, words of columns sc-s..sc+s
         const int rlo = max(0, sr - s), rhi = min(BFS_WH - 1, sr + s);
         const int wlo = max(0, (sc - s) >> 5), whi = min(BFS_WW - 1, (sc + s) >> 5), nw = whi - wlo + 1;
@@ -344,29 +523,6 @@ __global__ __launch_bounds__(BFS_THREADS) void mask_bfs_kernel(
             const int r = rlo + rr, w = wlo + (e - rr * nw);
             const unsigned int *row = cur + r * BFS_WW;
             unsigned int v;
-            if (tight_mode) {
-                v = row[w];
-                const int gy = wy0 + r, gw = (wx0 >> 5) + w;
-                if (gy >= 0 && gy < H && gw >= 0 && gw < Ww) {
-                    const unsigned int *tw = tg + (long)gy * Ww + gw;
-                    const long dstride = (long)H * Ww;
-                    const int oy8[8] = {-1, 1, 0, 0, -1, -1, 1, 1}, ox8[8] = {0, 0, -1, 1, -1, 1, -1, 1};
-                    for (int d = 0; d < ndir; ++d) {
-                        const int rp = r + oy8[d];
-                        if (rp < 0 || rp >= BFS_WH) continue;
-                        const unsigned int *prow = cur + rp * BFS_WW;
-                        const unsigned int c0 = prow[w];
-                        unsigned int from;
-                        if (ox8[d] < 0) from = (c0 << 1) | (w > 0 ? prow[w - 1] >> 31 : 0u);
-                        else if (ox8[d] > 0) from = (c0 >> 1) | (w + 1 < BFS_WW ? prow[w + 1] << 31 : 0u);
-                        else from = c0;
-                        if (from) v |= from & tw[d * dstride];
-                    }
-                }
-                nxt[r * BFS_WW + w] = v;
-                changed |= (v != row[w]);
-                continue;
-            }
             if (conn8) {
                 v = dil_h(row, w);
                 if (r > 0) v |= dil_h(row - BFS_WW, w);
@@ -380,7 +536,13 @@ __global__ __launch_bounds__(BFS_THREADS) void mask_bfs_kernel(
             nxt[r * BFS_WW + w] = v;
             changed |= (v != row[w]);
         }
-        const int any = __syncthreads_or(changed);
+        if (changed) s_step[s % 3][0] = 1;
+        if (my_open) s_step[s % 3][1] = 1;
+        __syncthreads();
+        const int both = s_step[s % 3][0] | (s_step[s % 3][1] << 1);
+        if (tid == 0) s_step[(s + 2) % 3][0] = s_step[(s + 2) % 3][1] = 0;
+        if (!(both & 2)) break;
+        my_open = 0;
         for (int e = tid; e < max_gap * cap; e += BFS_THREADS) {
             const int pos = tpos[e];
             if (pos < 0) continue;
@@ -388,12 +550,12 @@ __global__ __launch_bounds__(BFS_THREADS) void mask_bfs_kernel(
             if (nxt[r * BFS_WW + (c >> 5)] >> (c & 31) & 1u) {
                 tres[e] = (short)(s + 1);
                 tpos[e] = -1;
-                atomicSub(&n_open, 1);
+            } else {
+                my_open = 1;
             }
         }
-        __syncthreads();
         unsigned int *sw = cur; cur = nxt; nxt = sw;
-        if (!any) break;
+        if (!(both & 1)) break;
     }
     __syncthreads();
     for (int e = tid; e < max_gap * cap; e += BFS_THREADS) {
@@ -683,7 +845,12 @@ int axt_masked_distance_table(const axt_grid *g, const int32_t *d_x, const int32
 {
     for (int k = 0; k < max_gap; ++k)
         AXT_REQUIRE(h_dmax[k] - 1 <= BFS_R, "masked arcs: dmax %d exceeds the BFS window (%d cells)", h_dmax[k], BFS_R + 1);
-    const size_t lds = (size_t)3 * BFS_WH * BFS_WW * 4 + (size_t)max_gap * cap * 6 + 16;
+    // sources off the mask run two wavefronts (a fourth bitmap and a third per-target array) when that fits the LDS and
+    // the mask has its component fields; otherwise they take the windowed search as before
+    const size_t lds4 = (size_t)4 * BFS_WH * BFS_WW * 4 + (size_t)max_gap * cap * 8 + 16;
+    const int off_mode_ok = (g->d_tight != nullptr && g->d_off != nullptr && g->n_comp >= 1 && lds4 <= 159 * 1024 &&
+                             !getenv("AXT_PATH_NO_OFFMODE")) ? 1 : 0;
+    const size_t lds = off_mode_ok ? lds4 : (size_t)3 * BFS_WH * BFS_WW * 4 + (size_t)max_gap * cap * 6 + 16;
     AXT_REQUIRE(lds <= 159 * 1024, "masked arcs: cap %d needs %zu bytes of LDS", cap, lds);
     static bool attr = false;
     if (!attr) {
@@ -691,7 +858,8 @@ int axt_masked_distance_table(const axt_grid *g, const int32_t *d_x, const int32
         attr = true;
     }
     hipLaunchKernelGGL(mask_bfs_kernel, dim3(cap, n_frames), dim3(BFS_THREADS), lds, st, d_x, d_y, d_count, d_src_count, n_frames, cap, g->d_bits,
-                       g->d_label, g->H, g->W, g->Ww, g->conn8, max_dist, max_gap, d_dmax, d_Dtmp, (const unsigned int *)g->d_tight);
+                       g->d_label, g->H, g->W, g->Ww, g->conn8, max_dist, max_gap, d_dmax, d_Dtmp, (const unsigned int *)g->d_tight,
+                       (const unsigned char *)g->d_off, g->n_comp, off_mode_ok);
     AXT_LAUNCH_CHECK();
     int *flags = nullptr, *n_flagged = nullptr;
     AXT_CHECK_HIP(hipMallocAsync((void **)&flags, sizeof(int) * ((size_t)n_frames * cap + 1), st));

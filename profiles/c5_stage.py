@@ -34,3 +34,11 @@ for rep in range(2):
     ad.assign_ids()
     t = stamp(f'assign_ids #{rep} (arcs + flow solve)', t)
 print('tracks', ad.n_ids, flush=True)
+# the arc build alone (masked path searches + CSR), as assign_ids calls it
+from axtrack_amd import hotpath as hp
+from axtrack_amd.detections import _cost_units_on_device
+dmax, units = _cost_units_on_device(P, ad.max_px_assoc_dist, ad.device)
+for rep in range(2):
+    t = time.perf_counter()
+    arcs = hp.build_arcs(ad.d_x, ad.d_y, ad.d_count, 1024, 1024, dmax, units, grid, ad.max_px_assoc_dist, ad.conn8)
+    t = stamp(f'build_arcs #{rep} ({int(arcs[1].numel())} arcs)', t)
