@@ -7,7 +7,6 @@ import numpy as np
 import torch
 
 from . import _lib
-from . import synth
 
 TILE, S, CELLS = 512, 12, 144
 CONF_FLOOR = float(np.float32(0.55))   # all_conf_thrs.min() as f32 (AxonDetections.py:76,122)
@@ -24,10 +23,15 @@ def _require_gpu():
         raise _lib.AxtError('axtrack_amd needs a ROCm GPU (MI355X, gfx950); there is no CPU path')
 
 
+# ConvBlock_i modules of the deployed ARCHITECTURE that hold a convolution (blocks 3, 6, 9 are the max-pools;
+# deployed_model/params.txt:34, model.py:85-103)
+CONV_BLOCKS = (0, 1, 2, 4, 5, 7, 8, 10)
+
+
 def state_dict_tensor_order():
     """Key order axt_detector_create expects (include/axtrack_hip.h)."""
     keys = []
-    for name in synth.conv_block_names():
+    for name in (f'ConvBlock_{i}' for i in CONV_BLOCKS):
         for k in ('conv.weight', 'conv.bias', 'batchnorm.weight', 'batchnorm.bias',
                   'batchnorm.running_mean', 'batchnorm.running_var'):
             keys.append(f'ConvNet.{name}.{k}')
