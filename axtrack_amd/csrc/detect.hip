@@ -164,6 +164,132 @@ __global__ __launch_bounds__(256) void decode_stitch_nms_kernel(
     if (tid == 0) o_count[frame] = base_sh;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same for frames of more than 28 kept tiles (4096 x 4096 = 64 tiles, up to the 256 the detector takes): the
+// candidate arrays live in a per-frame workspace in HBM instead of LDS, and only the candidates that pass the
+// threshold are ranked (the rank is a count over pairs: quadratic in what is ranked). Same order, same arithmetic, same
+// result as the LDS kernel -- the reference has no size limit (AxonDetections.py:111-133).
+// workspace per frame: kept conf/x/y/idx [ncand], sorted conf/x/y [ncand], state [ncand]  (8 x ncand x 4 bytes)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void decode_stitch_nms_big_kernel(
+    const float *__restrict__ yolo, int n_tiles, TileOrigins tiles, float conf_thr, int thr2, int cap,
+    float *__restrict__ o_conf, int *__restrict__ o_x, int *__restrict__ o_y, int *__restrict__ o_count,
+    unsigned char *__restrict__ work)
+{
+    const int ncand = n_tiles * AXT_CELLS;
+    const int frame = blockIdx.x, tid = threadIdx.x;
+    float *k_conf = reinterpret_cast<float *>(work + (size_t)frame * ncand * 32);
+    int *k_x = reinterpret_cast<int *>(k_conf + ncand);
+    int *k_y = k_x + ncand;
+    int *k_idx = k_y + ncand;
+    float *s_conf = reinterpret_cast<float *>(k_idx + ncand);
+    int *s_x = reinterpret_cast<int *>(s_conf + ncand);
+    int *s_y = s_x + ncand;
+    int *state = s_y + ncand;
+    __shared__ int wave_tot[4], base_sh;
+    const float *yf = yolo + (long)frame * n_tiles * AXT_YOLO_FLOATS;
+    const int lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base_sh = 0;
+    __syncthreads();
+
+    // ---- decode, threshold, keep in (tile, cell) order (block-wide scan per 256 candidates)
+    for (int c0 = 0; c0 < ncand; c0 += 256) {
+        const int c = c0 + tid;
+        float conf = 0.f;
+        int px = 0, py = 0;
+        bool keep = false;
+        if (c < ncand) {
+            const int k = c / AXT_CELLS, cell = c - k * AXT_CELLS;
+            const int i = cell / AXT_S, j = cell - i * AXT_S;
+            conf = yf[c * 3 + 0];
+            const float xin = yf[c * 3 + 1], yin = yf[c * 3 + 2];
+            const bool zero = (conf == 0.f) && (xin == 0.f) && (yin == 0.f);
+            float xf = rintf(__fdiv_rn(__fmul_rn(__fadd_rn(xin, (float)i), (float)AXT_TILE), (float)AXT_S));
+            float yf2 = rintf(__fdiv_rn(__fmul_rn(__fadd_rn(yin, (float)j), (float)AXT_TILE), (float)AXT_S));
+            if (zero) { xf = 0.f; yf2 = 0.f; }
+            px = (int)xf + tiles.yx[2 * k + 1] * AXT_TILE;
+            py = (int)yf2 + tiles.yx[2 * k] * AXT_TILE;
+            keep = conf >= conf_thr;
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) wave_tot[wave] = __popcll(m);
+        __syncthreads();
+        int off = base_sh;
+        for (int w = 0; w < wave; ++w) off += wave_tot[w];
+        if (keep) {
+            const int o = off + __popcll(m & ((1ull << lane) - 1ull));
+            k_conf[o] = conf; k_x[o] = px; k_y[o] = py; k_idx[o] = c;
+        }
+        __syncthreads();
+        if (tid == 0) base_sh += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        __syncthreads();
+    }
+    const int n = base_sh;
+    __syncthreads();
+    if (tid == 0) base_sh = 0;
+
+    // ---- rank by descending confidence, ties in (tile, cell) order (kept candidates are already in that order)
+    for (int c = tid; c < n; c += 256) {
+        const float conf = k_conf[c];
+        int rank = 0;
+        for (int o = 0; o < n; ++o) {
+            const float oc = k_conf[o];
+            rank += (oc > conf) || (oc == conf && o < c);
+        }
+        s_conf[rank] = conf;
+        s_x[rank] = k_x[c];
+        s_y[rank] = k_y[c];
+        state[rank] = ST_UNDECIDED;
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- greedy NMS in parallel rounds (as above)
+    for (int round = 0; round <= n; ++round) {
+        int pending_any = 0;
+        for (int i = tid; i < n; i += 256) {
+            if (__hip_atomic_load(&state[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != ST_UNDECIDED) continue;
+            const int xi = s_x[i], yi = s_y[i];
+            int st = ST_ALIVE;
+            for (int j = 0; j < i; ++j) {
+                const int dx = s_x[j] - xi, dy = s_y[j] - yi;
+                if (dx * dx + dy * dy < thr2) {
+                    const int sj = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (sj == ST_ALIVE) { st = ST_DEAD; break; }
+                    if (sj == ST_UNDECIDED) st = ST_UNDECIDED;
+                }
+            }
+            if (st == ST_UNDECIDED) pending_any = 1;
+            else __hip_atomic_store(&state[i], st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __threadfence_block();
+        if (!__syncthreads_or(pending_any)) break;
+    }
+    __syncthreads();
+
+    // ---- compact survivors in order
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + tid;
+        const int alive = (i < n) && (state[i] == ST_ALIVE);
+        const unsigned long long m = __ballot(alive);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[wave] = __popcll(m);
+        __syncthreads();
+        int off = base_sh;
+        for (int w = 0; w < wave; ++w) off += wave_tot[w];
+        if (alive) {
+            const long o = (long)frame * cap + off + before;
+            o_conf[o] = s_conf[i];
+            o_x[o] = s_x[i];
+            o_y[o] = s_y[i];
+        }
+        __syncthreads();
+        if (tid == 0) base_sh += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        __syncthreads();
+    }
+    if (tid == 0) o_count[frame] = base_sh;
+}
+
 }  // namespace
 
 extern "C" {
@@ -198,8 +324,7 @@ int axt_decode_stitch_nms(const float *d_yolo, int n_frames, int n_tiles, const 
                           void *stream)
 {
     AXT_REQUIRE(d_yolo && h_tile_yx && d_conf && d_x && d_y && d_count, "null argument");
-    AXT_REQUIRE(n_tiles >= 1 && n_tiles <= 28, "n_tiles %d: this kernel keeps a frame's candidates in LDS (max 28 tiles)",
-                n_tiles);
+    AXT_REQUIRE(n_tiles >= 1 && n_tiles <= 256, "n_tiles %d out of range (1..256)", n_tiles);
     AXT_REQUIRE(cap >= n_tiles * AXT_CELLS, "cap %d < n_tiles*144 = %d", cap, n_tiles * AXT_CELLS);
     AXT_REQUIRE(min_dist >= 0 && min_dist < 32768, "min_dist out of range");
     if (n_frames <= 0) return AXT_OK;
@@ -208,6 +333,17 @@ int axt_decode_stitch_nms(const float *d_yolo, int n_frames, int n_tiles, const 
     for (int k = 0; k < n_tiles; ++k) {
         tiles.yx[2 * k] = (short)h_tile_yx[2 * k];
         tiles.yx[2 * k + 1] = (short)h_tile_yx[2 * k + 1];
+    }
+    if (n_tiles > 28) {                         // candidates of a frame do not fit the LDS: workspace in HBM
+        const size_t per_frame = (size_t)n_tiles * AXT_CELLS * 32;
+        hipStream_t st = (hipStream_t)stream;
+        unsigned char *work = nullptr;
+        AXT_CHECK_HIP(hipMallocAsync((void **)&work, per_frame * (size_t)n_frames, st));
+        hipLaunchKernelGGL(decode_stitch_nms_big_kernel, dim3(n_frames), dim3(256), 0, st, d_yolo, n_tiles, tiles, conf_thr,
+                           min_dist * min_dist, cap, d_conf, d_x, d_y, d_count, work);
+        AXT_LAUNCH_CHECK();
+        AXT_CHECK_HIP(hipFreeAsync(work, st));
+        return AXT_OK;
     }
     const size_t lds = (size_t)n_tiles * AXT_CELLS * 7 * 4;
     static bool attr = false;

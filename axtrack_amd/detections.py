@@ -102,6 +102,13 @@ class AxonDetections(object):
         thr = float(np.float32(self.all_conf_thrs.min()))
         self.d_conf, self.d_x, self.d_y, self.d_count = hp.decode_stitch_nms(
             self._yolo, self.tile_yx, thr, self.nms_min_dist)
+        import torch.distributed as dist
+        if self.d_conf.shape[1] > 2048 and not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            # large frames (more than 14 tiles): the arrays were sized for one detection per grid cell; keep what the fullest
+            # frame needs (the arc builder's scratch and the frame-to-frame variant scale with the capacity)
+            cap = max(int(self.d_count.max().item()), 1)
+            cap = min(-(-cap // 64) * 64, int(self.d_conf.shape[1]))
+            self.d_conf, self.d_x, self.d_y = (a[:, :cap].contiguous() for a in (self.d_conf, self.d_x, self.d_y))
         self._det_tables = None
         self._host = None
         if cache == 'to':

@@ -126,6 +126,8 @@ int axt_tile_occupancy(const float *d_frames, int T_all, int H, int W, uint8_t *
  * d_yolo f32 [n_frames, n_tiles, 12,12,3]; h_tile_yx i32 [n_tiles,2] (tile row, tile col).
  * Outputs, capacity cap >= n_tiles*144 per frame: d_conf f32, d_x i32, d_y i32 [n_frames,cap]
  * in descending confidence (ties: tile order, then cell order), d_count i32 [n_frames].
+ * n_tiles <= 256; frames of up to 28 kept tiles keep their candidates in LDS, larger ones in a workspace in HBM
+ * (allocated on the stream for the call): same order, same result.
  * ------------------------------------------------------------------------------------------ */
 int axt_decode_stitch_nms(const float *d_yolo, int n_frames, int n_tiles, const int32_t *h_tile_yx,
                           float conf_thr, int min_dist, int cap,

@@ -1391,3 +1391,42 @@ def test_inference_with_bf16x3_parameter(weights):
     ref = orc.inference(frames, weights, P=dict(orc.DEFAULTS, MCF_MIN_FLOW=1), yolo=list(yolo))
     _assert_dets_equal_oracle(ad, ref['dets'])
     assert tracks_from_next(np.zeros(len(ad._track_flat)), ad._track_flat, ad._offs) == ref['trajs']
+
+
+# ----------------------------------------------------------------------------------------- frames of more than 28 tiles
+def test_decode_stitch_nms_on_frames_of_more_than_28_tiles():
+    """The reference has no frame-size limit (AxonDetections.py:111-133); frames of up to 28 kept tiles keep their
+    candidates in LDS, larger ones (here 6 x 7 = 42 tiles: 6 048 candidates per frame) in a workspace in HBM. Random grids
+    with about half of the cells above the floor, exact ties and clusters closer than the NMS distance: bit-exact
+    against the oracle."""
+    rng = np.random.default_rng(8)
+    keep = [(r, c) for r in range(6) for c in range(7)]
+    yolo = rng.uniform(0, 1, (3, len(keep), 12, 12, 3)).astype(np.float32)
+    yolo[..., 0] = rng.uniform(0.1, 1.0, yolo.shape[:-1])
+    yolo[1, :, ::2, :, 0] = np.float32(0.8125)                        # exact ties: (tile, cell) order decides
+    yolo[2, :, :, :, 1:] *= 0.05                                       # anchors crowd the cell corners: chains of suppressions
+    yolo[2, 5] = 0                                                     # an all-zero tile stays at its origin and below the floor
+    conf, x, y, cnt = [t.cpu().numpy() for t in hp.decode_stitch_nms(dev(yolo), keep)]
+    ref = orc.detect_from_yolo(list(yolo), keep)
+    for t, (rc, rx, ry) in enumerate(ref):
+        n = int(cnt[t])
+        assert n == len(rc) and n > 1500, (t, n, len(rc))
+        assert np.array_equal(conf[t, :n].view(np.uint32), np.asarray(rc, np.float32).view(np.uint32)), t
+        assert np.array_equal(x[t, :n], rx) and np.array_equal(y[t, :n], ry), t
+
+
+def test_inference_on_a_frame_of_thirty_tiles(weights):
+    """2560 x 3072 frames (5 x 6 tiles, beyond the LDS kernel's 28): the whole path, detection arrays shrunk to what the
+    fullest frame needs; detections and the flow tracker's trajectories equal the oracle's given the detector's grids."""
+    import axtrack_amd
+    frames = synth.synth_frames(6, 2560, 3072, seed=4)
+    model = axtrack_amd.Detector(weights, max_batch=64)
+    P = dict(params.load_parameters(), MCF_MIN_FLOW=1)
+    ad = axtrack_amd.inference(axtrack_amd.Timelapse(frames, name='big'), model, None, P, None, None, None)
+    assert len(ad.tile_yx) == 30 and ad.d_conf.shape[1] < 30 * 144
+    yolo = ad._yolo.cpu().numpy()
+    ref = orc.inference(frames, weights, P=dict(orc.DEFAULTS, MCF_MIN_FLOW=1), yolo=list(yolo), name='big')
+    _assert_dets_equal_oracle(ad, ref['dets'])
+    assert tracks_from_next(np.zeros(len(ad._track_flat)), ad._track_flat, ad._offs) == ref['trajs']
+    assert ad.mcf_total_cost == ref['total_cost']
+    np.testing.assert_allclose(yolo[1, 17], orc.cnn_forward(weights, orc.frame_tile_stack(frames, 1, ad.tile_yx))[17], atol=CNN_ATOL, rtol=CNN_RTOL)
