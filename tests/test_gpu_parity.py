@@ -1430,3 +1430,33 @@ def test_inference_on_a_frame_of_thirty_tiles(weights):
     assert tracks_from_next(np.zeros(len(ad._track_flat)), ad._track_flat, ad._offs) == ref['trajs']
     assert ad.mcf_total_cost == ref['total_cost']
     np.testing.assert_allclose(yolo[1, 17], orc.cnn_forward(weights, orc.frame_tile_stack(frames, 1, ad.tile_yx))[17], atol=CNN_ATOL, rtol=CNN_RTOL)
+
+
+def test_ided_cache_round_trip_with_more_than_a_thousand_identities(tmp_path):
+    """'_IDed_detections' written and read back (AxonDetections.py:141-176) with identities above 999: the names are
+    zero-padded to three digits, not truncated ('Axon_1234'), so the reference's `int(name[-3:])` would fold 1234 onto 234;
+    the round trip must keep every identity apart."""
+    import pandas as pd
+    import axtrack_amd
+    from axtrack_amd.detections import AxonDetections
+    rng = np.random.default_rng(2)
+    F, per = 6, 260
+    tl = axtrack_amd.Timelapse(np.zeros((F + 4, 512, 512), np.float32), name='many')
+    ad = AxonDetections(None, tl, params.load_parameters(), str(tmp_path))
+    cells = rng.permutation(500 * 500)[:per]
+    tabs = [pd.DataFrame({'conf': np.sort(rng.uniform(0.6, 1.0, per).astype(np.float32))[::-1],
+                          'anchor_x': (cells % 500 + f).astype(np.int64), 'anchor_y': (cells // 500).astype(np.int64)}) for f in range(F)]
+    ad._set_detections_from_tables(tabs)
+    # every detection its own identity: 1560 tracks of length one, numbered in flat order
+    ad._track_flat_cache, ad._d_track, ad.n_ids = np.arange(F * per, dtype=np.int32), None, F * per
+    ad._solved, ad._ided_tables = True, None
+    first = ad._agg_all_IDed_dets()
+    assert first.shape == (F * per, 3 * F) and first.index[1234] == 'Axon_1234'
+    ad.to_cache('_IDed_detections', ad._IDed_detections)
+    again = AxonDetections(None, tl, params.load_parameters(), str(tmp_path))
+    again._set_detections_from_tables(tabs)
+    again.assign_ids(assigedIDs_cache='from')
+    assert np.array_equal(again._track_flat, ad._track_flat)
+    pd.testing.assert_frame_equal(again.IDed_dets_all, first)
+    rows = again.get_frame_dets('IDed', None, libmot=True)
+    assert sorted(set(rows.index.get_level_values('Id'))) == list(range(F * per))
