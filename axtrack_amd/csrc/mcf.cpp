@@ -328,6 +328,30 @@ struct Lsap {
             j = prev;
         }
         stat_rows += sr_rows.size();
+        // Reduction transfer (the dual tightening of Jonker-Volgenant's initialisation, applied after every search): a row
+        // raises its dual to its SECOND-best reduced cost and hands the difference to its matched column, whose dual
+        // drops -- still feasible (every other edge of the row keeps a non-negative reduced cost, every other row sees
+        // the column get dearer), still tight on the matched edge. The shortest-path update above leaves duals as
+        // shallow as feasibility allows, so columns keep looking cheap to rows that will never get them and later
+        // searches wander through them; tightened duals stop those searches at the first look. The inserted row always;
+        // every scanned row after a search that went further than a few rows (measured on the config-3 network, 16
+        // threads: 43 -> 34 ms; 224 k -> 150 k rows scanned).
+        auto transfer = [&](int r) {
+            Row &rr = rw[r];
+            const int m = rr.col;
+            int64_t best2 = INF, cm = 0;
+            auto see = [&](int j, int64_t w) {
+                if (j == m) cm = w;
+                else { const int64_t k = w - c[j].v; if (k < best2) best2 = k; }
+            };
+            see(r, 0);
+            see(n + r, rr.own);
+            const Arc *ap = arcs.data() + rr.arc_begin;
+            for (int k = 0; k < rr.degree; ++k) see(ap[k].head, rr.base + ap[k].w);
+            if (best2 < INF && best2 > rr.u) { rr.u = best2; c[m].v = cm - best2; }
+        };
+        if (sr_rows.size() > 8) for (int32_t r : sr_rows) transfer(r);
+        else transfer(i);
     }
 
     // rows in a fixed pseudo-random order (xorshift64 seeded by the first row: the same at any thread count)
