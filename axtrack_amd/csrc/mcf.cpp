@@ -198,6 +198,24 @@ struct Lsap {
     std::vector<Col> c;
     std::vector<Row> rw;
     std::vector<Arc> arcs;
+    // Two phases (a continuation in the entry / exit cost). Ending a track costs entry + exit = 4 cost units against
+    // 0.002-0.7 for a link: a row that has to end a track finds its nearest free column, the private exit, only after
+    // a search ball of reduced radius ~4 -- on dense timelapses the whole neighbourhood -- and every track end near the
+    // END of the timelapse pays that (the right spine of the time-block tree: 30 of 32 ms on config 3). The first phase
+    // therefore solves the problem with the exits at a fifth of their price: balls stay small, the blocks of the tree
+    // join in a few ms. For a fixed number of tracks the optimum does not depend on that price at all (it adds a
+    // constant), so the second phase -- full price -- only has to reconsider the track ENDS: taken out and inserted
+    // afresh, serially (config 3: 81 ends, of which 63 stay and 18 tracks dissolve; 152 k -> 101 k rows scanned).
+    // Measured on the GPU box's host (16 threads), one phase -> two: config 3 (19 k detections) 33.5 -> 22.2 ms, one GPU's share
+    // of config 4 (40 k) 265 -> 157 ms, of config 5 (20 k, masked) 70 -> 50 ms; a 309 k-detection timelapse 1.28 -> 1.65 s
+    // (its 441 track ends, re-inserted serially, cost more than the tree saves): two phases up to 120 k detections.
+    bool two_phase = false;
+    inline int64_t discount(int k) const
+    {
+        if (!two_phase) return 0;
+        const int64_t whole = ((entry[k] + exitc[k]) >> 16) / 5 * 4;      // four fifths of entry + exit, in whole cost units
+        return whole > 0 ? whole << 16 : 0;
+    }
     size_t stat_rows = 0, stat_relax = 0, stat_push = 0;
     std::mutex stat_lock;
 
@@ -423,6 +441,7 @@ struct Lsap {
     {
         const double t0 = now_ms();
         const int budget = thread_budget();
+        two_phase = getenv("AXT_MCF_TWO_PHASE") ? true : getenv("AXT_MCF_ONE_PHASE") ? false : n <= 120000;
         c.assign(2 * (size_t)n, Col{0, 0, -1, -1, -1, 0});
         rw.resize(n);
         arcs.resize((size_t)row_ptr[n]);
@@ -430,7 +449,7 @@ struct Lsap {
         auto setup = [&](int k0, int k1) {
             for (int k = k0; k < k1; ++k) {
                 const int64_t lo = row_ptr[k], hi = row_ptr[k + 1];
-                rw[k] = Row{0, obs[k] + entry[k], obs[k] + entry[k] + exitc[k], lo, (int32_t)(hi - lo), -1, -1, 0};
+                rw[k] = Row{0, obs[k] + entry[k], obs[k] + entry[k] + exitc[k] - discount(k), lo, (int32_t)(hi - lo), -1, -1, 0};
                 int32_t far = k;
                 for (int64_t e = lo; e < hi; ++e) {                             // insertion sort: rows are short
                     const int64_t w = cost[e] - entry[col[e]];
@@ -485,6 +504,26 @@ struct Lsap {
         }
         const double t1 = now_ms();
         solve_tree(0, leaves);
+        const double t2 = now_ms();
+        size_t ends = 0;
+        if (two_phase) {
+            // second phase: the exits get their full price back. Nothing else changes, so every dual stays feasible and
+            // every matched edge tight except those of the rows that sit on their exit column: those are taken out (their
+            // private column is free again) and inserted afresh.
+            std::vector<int32_t> again;
+            for (int k = 0; k < n; ++k) {
+                const bool at_exit = rw[k].col == n + k;
+                rw[k].own += discount(k);
+                if (at_exit && discount(k) > 0) again.push_back(k);
+            }
+            two_phase = false;
+            for (int32_t k : again) { c[n + k].row = -1; c[n + k].v = 0; rw[k].col = -1; rw[k].arc = -1; rw[k].u = 0; }
+            Search w(*this, 0x7f000000u);
+            for (int32_t k : again) w.insert_row(k);
+            ends = again.size();
+        }
+        if (getenv("AXT_MCF_DEBUG"))
+            fprintf(stderr, "lsap: second phase %zu track ends, %.1f ms; ", ends, now_ms() - t2);
         if (getenv("AXT_MCF_DEBUG"))
             fprintf(stderr, "lsap: n=%d threads<=%d leaves=%d rows scanned=%zu relax=%zu push=%zu  setup %.1f ms, insertions %.1f ms\n", n,
                     budget, leaves, stat_rows, stat_relax, stat_push, t1 - t0, now_ms() - t1);

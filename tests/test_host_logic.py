@@ -309,3 +309,32 @@ def test_sweep_solver_on_a_slice_of_config_3():
     ref = hp.mcf_solve(*args, 5, 450)
     res = hp.mcf_solve_dag(offs[:F + 1], *args, 5, 450)
     assert res[2] == ref[2] and res[3] == ref[3] and np.array_equal(res[0], ref[0]) and np.array_equal(res[1], ref[1])
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_flow_solver_one_and_two_phase_schedules_agree(seed, monkeypatch):
+    """The assignment solver's two-phase schedule (exits at a fifth of their price first, then the track ends re-inserted at
+    the full price) and the one-phase schedule return the oracle's trajectories and cost -- dense random timelapses where
+    tracks dissolve and merge between the phases, with flow bounds and time blocks."""
+    rng = np.random.default_rng(900 + seed)
+    F = int(rng.integers(6, 24))
+    dets = []
+    for t in range(F):
+        n = int(rng.integers(2, 11))
+        conf = np.sort(rng.uniform(0.55, 1.3, n).astype(np.float32))[::-1]
+        dets.append((conf, rng.integers(0, 150, n), rng.integers(0, 150, n)))
+    P = dict(orc.DEFAULTS, MCF_MIN_FLOW=int(rng.integers(0, 3)), MCF_MAX_FLOW=int(rng.integers(3, 40)),
+             MCF_ENTRY_EXIT_COST=float(rng.choice([0.3, 1.0, 2.0])))
+    trajs, total = orc.mcf_solve(dets, orc.all_path_matrices(dets, 400, 400), P)
+    monkeypatch.setenv('AXT_MCF_MIN_LEAF', '4')
+    for env in ('AXT_MCF_ONE_PHASE', 'AXT_MCF_TWO_PHASE'):
+        monkeypatch.delenv('AXT_MCF_ONE_PHASE', raising=False)
+        monkeypatch.delenv('AXT_MCF_TWO_PHASE', raising=False)
+        monkeypatch.setenv(env, '1')
+        for threads in ('1', '8'):
+            monkeypatch.setenv('AXT_MCF_THREADS', threads)
+            res, offs = _solve(dets, 400, 400, P)
+            if trajs is None:
+                assert res is None
+                continue
+            assert res[3] == total and tracks_from_next(res[0], res[1], offs) == trajs
