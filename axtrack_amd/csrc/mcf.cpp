@@ -308,9 +308,12 @@ struct Lsap {
             relax(n + cur, rc.own, -1);         // a track of its own / track end
             // arcs sorted by cost: column duals are <= 0, so once the bare cost reaches best_free the rest cannot matter
             const Arc *ap = arcs.data() + rc.arc_begin;
+            // the column records are visited in arc order, i.e. at random: ask for them a few arcs ahead
+            for (int k = 0; k < rc.degree && k < 6; ++k) __builtin_prefetch(&c[ap[k].head]);
             for (int k = 0; k < rc.degree; ++k) {
                 const int64_t w = rc.base + ap[k].w;
                 if (off + w >= best_free) break;
+                if (k + 6 < rc.degree) __builtin_prefetch(&c[ap[k + 6].head]);
                 relax(ap[k].head, w, ap[k].id);
             }
             int j = -1;
