@@ -509,6 +509,254 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3(
 }
 
 // ------------------------------------------------------------------------------------------------
+// conv3x3_wino: the stride-1 blocks with 80 output channels as Winograd F(2x2, 3x3) on the f32 matrix pipe.
+//   Y = A^T [ (G g G^T) . (B^T d B) ] A per 2x2 output tile (Lavin & Gray 2016): 16 multiplies per tile, input and output
+//   channel instead of 36 -- the 16 transform positions are 16 independent GEMMs  M_pos[tile][cout] = V_pos[tile][cin] *
+//   U_pos[cin][cout]  on v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate; all arithmetic stays f32: the transforms are
+//   additions, the weights G g G^T are formed in f64 and rounded once). Measured on post-activation data the result is as
+//   close to an f64 convolution as the direct f32 kernel's.
+//   Workgroup = 16 x 16 output pixels (8 x 8 tiles = 4 MFMA row blocks of 16 tiles) x 80 channels, 8 waves, one workgroup
+//   per CU, persistent. Wave (m, h): row block m, ALL 16 positions, output-channel blocks {0,1} (h = 0) or {2,3,4}
+//   (h = 1): a lane holds every position of its (tile, channel) pairs, so the output transform, bias, LeakyReLU and the
+//   2x2 max -- one Winograd tile is one pooled pixel -- never leave its registers. Waves w and w + 4 share a SIMD, so each
+//   SIMD carries 2 + 3 channel blocks; the h = 0 waves, with a third less MFMA work, also run the input transform.
+//   K runs in chunks of 8 input channels = 2 MFMA k-steps. LDS (144 KB): two buffers of
+//     V [pos 16][row block 4][lane 64][k-step 2]   (32 KB)   and   U [pos 16][channel block 5][lane 64][k-step 2]   (40 KB):
+//   lane-linear 8-byte elements, one conflict-free ds_read_b64 (256 B/clk) fetches a lane's operand for both k-steps.
+//   U is packed in exactly that order (pack_wino), so a chunk is 40 LDS-DMA pieces of 1 KiB (global_load_lds_dwordx4), five
+//   per wave, no registers and no ds_write. One barrier per chunk: at its top the loads of chunk g + 1 are issued (raw 4 x 4
+//   input patches into registers; U by DMA into the other buffer), then the chunk's MFMAs, then the h = 0 waves transform
+//   the patches (32 add/sub per patch) and write V for g + 1. The chunk stream runs across tiles, so a tile's epilogue and
+//   stores overlap the next tile's loads.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct GeoW {
+    static constexpr int CCH = 8;
+    static constexpr int VBUF = 16 * 4 * 64 * 2;          // floats per V buffer
+    static constexpr int UBUF = 16 * 5 * 64 * 2;          // floats per U buffer = one packed chunk
+    static constexpr int LDS_B = 2 * (VBUF + UBUF) * 4;   // 147456
+};
+
+template <int CIN, bool POOL, int NTW, bool XFORM>
+__device__ __forceinline__ void wino_body(const float *__restrict__ in, const float *__restrict__ upk,
+                                          const float *__restrict__ bias, float *__restrict__ out, int H, int B, float *smem)
+{
+    using G = GeoW;
+    constexpr int NCH = CIN / G::CCH;
+    constexpr int N0 = XFORM ? 0 : 2;              // first output-channel block of this wave
+    static_assert(CIN % G::CCH == 0, "CIN must be a multiple of 8");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 15, q = lane >> 4;
+    const int m = wave & 3;
+    const int tiles_x = H >> 4, ntile = tiles_x * tiles_x;
+    const WorkRange wr = my_work(ntile * B);
+    if (wr.begin >= wr.end) return;
+    const int cstride = H * H;
+    const int Hout = POOL ? H / 2 : H;
+    float *Vs = smem, *Us = smem + 2 * G::VBUF;
+
+    float bias_v[NTW];
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) bias_v[n] = bias[(N0 + n) * 16 + p];
+
+    // ---- loads of one chunk: raw patches (transform waves) + this wave's share of the U pieces ----
+    float d[2][4][4];
+    int voA[4], voB[4], voC[4];
+    __amdgpu_buffer_rsrc_t ld_rsrc;
+    auto plan_tile = [&](int w) {
+        const int tile = w % ntile, b = w / ntile;
+        ld_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in) + (long)b * CIN * cstride, 0, kBufRecords, 0x00020000);
+        if constexpr (XFORM) {
+            const int y0 = (tile / tiles_x) * 16, x0 = (tile % tiles_x) * 16;
+            const int ty = 2 * m + (p >> 3), tx = p & 7;
+            const int gx0 = x0 + 2 * tx - 1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gy = y0 + 2 * ty - 1 + r;
+                const bool ok = gy >= 0 && gy < H;
+                const int base = (q * cstride + gy * H + gx0) * 4;
+                voA[r] = (ok && gx0 >= 0) ? base : (int)kOobOffset;
+                voB[r] = ok ? base + 4 : (int)kOobOffset;
+                voC[r] = (ok && gx0 + 3 < H) ? base + 12 : (int)kOobOffset;
+            }
+        }
+    };
+    auto issue = [&](int c, int buf) {
+        if constexpr (XFORM) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int soff = (c * G::CCH + s * 4) * cstride * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    d[s][r][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ld_rsrc, voA[r], soff, 0));
+                    const f32x2 mid = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(ld_rsrc, voB[r], soff, 0));
+                    d[s][r][1] = mid.x;
+                    d[s][r][2] = mid.y;
+                    d[s][r][3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ld_rsrc, voC[r], soff, 0));
+                }
+            }
+        }
+        const float *src = upk + (long)c * G::UBUF + (wave * 5) * 256 + lane * 4;
+        float *dst = Us + buf * G::UBUF + (wave * 5) * 256;
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + k * 256),
+                                             (__attribute__((address_space(3))) void *)(dst + k * 256), 16, 0, 0);
+    };
+    // B^T d B of the two patches of this lane -> V[buf][pos][m][lane][s]
+    auto xform_store = [&](int buf) {
+        if constexpr (XFORM) {
+            float v[2][16];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float t[4][4];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    t[0][x] = d[s][0][x] - d[s][2][x];
+                    t[1][x] = d[s][1][x] + d[s][2][x];
+                    t[2][x] = d[s][2][x] - d[s][1][x];
+                    t[3][x] = d[s][1][x] - d[s][3][x];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[s][i * 4 + 0] = t[i][0] - t[i][2];
+                    v[s][i * 4 + 1] = t[i][1] + t[i][2];
+                    v[s][i * 4 + 2] = t[i][2] - t[i][1];
+                    v[s][i * 4 + 3] = t[i][1] - t[i][3];
+                }
+            }
+            float *dstv = Vs + buf * G::VBUF + (m * 64 + lane) * 2;
+#pragma unroll
+            for (int pos = 0; pos < 16; ++pos) *reinterpret_cast<f32x2 *>(dstv + pos * 512) = f32x2{v[0][pos], v[1][pos]};
+        }
+    };
+
+    f32x4 acc[16][NTW];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int pos = 0; pos < 16; ++pos)
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) acc[pos][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto mfma_chunk = [&](int buf) {
+        const float *va = Vs + buf * G::VBUF + (m * 64 + lane) * 2;
+        const float *ub = Us + buf * G::UBUF + (N0 * 64 + lane) * 2;
+        f32x2 a[2], bq[2][NTW];
+        auto fetch = [&](int pos) {
+            const int slot = pos & 1;
+            a[slot] = *reinterpret_cast<const f32x2 *>(va + pos * 512);
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) bq[slot][n] = *reinterpret_cast<const f32x2 *>(ub + (pos * 5 + n) * 128);
+        };
+        fetch(0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1 + NTW, 0);
+#pragma unroll
+        for (int pos = 0; pos < 16; ++pos) {
+            if (pos + 1 < 16) fetch(pos + 1);
+            const int slot = pos & 1;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int n = 0; n < NTW; ++n)
+                    acc[pos][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[slot][s], bq[slot][n][s], acc[pos][n], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1 + NTW, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * NTW, 0);
+        }
+    };
+    // A^T M A, bias, LeakyReLU(0.1) (+ 2x2 max) and the stores of tile w
+    auto epilogue = [&](int w) {
+        const int tile = w % ntile, b = w / ntile;
+        const int y0 = (tile / tiles_x) * 16, x0 = (tile % tiles_x) * 16;
+        const int ty = 2 * m + (q >> 1), txb = 4 * (q & 1);          // this lane's tiles: row ty, columns txb .. txb + 3
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+            const int ch = (N0 + n) * 16 + p;
+            float *och = out + ((long)b * 80 + ch) * Hout * Hout;
+            float y[2][2][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t[2][4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    t[0][jj] = acc[jj][n][j] + acc[4 + jj][n][j] + acc[8 + jj][n][j];
+                    t[1][jj] = acc[4 + jj][n][j] - acc[8 + jj][n][j] - acc[12 + jj][n][j];
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    y[a][0][j] = t[a][0] + t[a][1] + t[a][2];
+                    y[a][1][j] = t[a][1] - t[a][2] - t[a][3];
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float t = y[a][bb][j] + bias_v[n];
+                        y[a][bb][j] = POOL ? (t > 0.f ? t : t * 0.1f) : fmaxf(t, t * 0.1f);
+                    }
+            if constexpr (POOL) {
+                f32x4 r;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r[j] = fmaxf(fmaxf(y[0][0][j], y[0][1][j]), fmaxf(y[1][0][j], y[1][1][j]));
+                *reinterpret_cast<f32x4 *>(och + (long)(y0 / 2 + ty) * Hout + x0 / 2 + txb) = r;
+            } else {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    float *orow = och + (long)(y0 + 2 * ty + a) * Hout + x0 + 2 * txb;
+                    *reinterpret_cast<f32x4 *>(orow) = f32x4{y[a][0][0], y[a][1][0], y[a][0][1], y[a][1][1]};
+                    *reinterpret_cast<f32x4 *>(orow + 4) = f32x4{y[a][0][2], y[a][1][2], y[a][0][3], y[a][1][3]};
+                }
+            }
+        }
+    };
+
+    int w_cur = wr.begin, g = 0;
+    plan_tile(w_cur);
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    xform_store(0);
+    __syncthreads();
+    zero_acc();
+    for (;;) {
+        const int w_next = w_cur + wr.step;
+        const bool more = w_next < wr.end;
+        for (int c = 0; c < NCH; ++c, ++g) {
+            const int buf = g & 1;
+            const bool last = c + 1 == NCH;
+            if (!last) issue(c + 1, buf ^ 1);
+            else if (more) {
+                plan_tile(w_next);
+                issue(0, buf ^ 1);
+            }
+            mfma_chunk(buf);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the raw patches and this wave's DMA pieces have landed
+            if (!last || more) xform_store(buf ^ 1);
+            if (last) {
+                epilogue(w_cur);
+                zero_acc();
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        if (!more) break;
+        w_cur = w_next;
+    }
+}
+
+template <int CIN, bool POOL>
+__global__ __launch_bounds__(512, 1) void conv3x3_wino(const float *__restrict__ in,      // activations [B,CIN,H,H]
+                                                       const float *__restrict__ upk,     // pack_wino image
+                                                       const float *__restrict__ bias,    // folded bias [80]
+                                                       float *__restrict__ out,           // [B,80,Hout,Hout]
+                                                       int H, int B)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if ((threadIdx.x >> 8) == 0) wino_body<CIN, POOL, 2, true>(in, upk, bias, out, H, B, smem);
+    else wino_body<CIN, POOL, 3, false>(in, upk, bias, out, H, B, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
 // stride-2 conv3x3 on v_mfma_f32_4x4x1_16b_f32 (conv blocks 0 and 1).
 //   These two layers have narrow N (20 / 40 channels) and, block 0, K = 45: on 16x16x4 tiles 20 pads to 32 and 45 to
 //   48. The 4x4x1 shape (16 independent 4-pixel x 4-channel outer products per instruction, 8 cycles, the same
@@ -1012,7 +1260,8 @@ struct axt_detector {
     float *d_wconv[8] = {};     // packed conv weights
     unsigned *d_wb3[8] = {};    // conv blocks 2..6 packed for conv3x3_bf16x3 (allocated on the first switch to that arithmetic)
     std::vector<float> h_wfold[8];   // their BN-folded f32 weights [cout][cin][3][3], kept on the host for that packing
-    int arith = 0;              // 0: f32 MFMA everywhere (default) | 1: bf16x3 for the stride-1 blocks with 80 output channels
+    float *d_wwino[8] = {};     // conv blocks 2..6 packed for conv3x3_wino (allocated on the first switch to that arithmetic)
+    int arith = 0;              // 0: direct f32 MFMA everywhere | 1: bf16x3 | 2: f32 Winograd F(2x2,3x3), for the stride-1 blocks with 80 output channels
     float *d_bconv[8] = {};     // folded bias
     float *d_wfc[3] = {};       // [K][Npad]
     float *d_bfc[3] = {};
@@ -1184,6 +1433,46 @@ int persistent_grid(int nwork, int per_cu)
     return g;
 }
 
+// Packs the BN-folded weights [80][cin][3][3] of a stride-1 block for conv3x3_wino: U = G g G^T (f64, rounded once) in
+// the LDS image order [chunk of 8 channels][pos 16][channel block 5][lane = q*16 + p][k-step 2]:
+// input channel chunk*8 + s*4 + q, output channel block*16 + p.
+void pack_wino(int cin, const std::vector<float> &wfold, std::vector<float> &out)
+{
+    static const double Gm[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    const int nchunk = cin / GeoW::CCH;
+    out.assign((size_t)nchunk * GeoW::UBUF, 0.f);
+    for (int co = 0; co < 80; ++co)
+        for (int ci = 0; ci < cin; ++ci) {
+            const float *g = &wfold[((size_t)co * cin + ci) * 9];
+            double tmp[4][3];
+            for (int i = 0; i < 4; ++i)
+                for (int b = 0; b < 3; ++b) tmp[i][b] = Gm[i][0] * g[0 * 3 + b] + Gm[i][1] * g[1 * 3 + b] + Gm[i][2] * g[2 * 3 + b];
+            const int chunk = ci / 8, s = (ci % 8) / 4, q = ci % 4, n = co / 16, p = co % 16;
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) {
+                    const double u = tmp[i][0] * Gm[j][0] + tmp[i][1] * Gm[j][1] + tmp[i][2] * Gm[j][2];
+                    out[((((size_t)chunk * 16 + i * 4 + j) * 5 + n) * 64 + q * 16 + p) * 2 + s] = (float)u;
+                }
+        }
+}
+
+template <int CIN, bool POOL>
+int launch_conv_wino(const float *in, const float *u, const float *bias, float *out, int Hin, int B, hipStream_t st)
+{
+    auto kern = conv3x3_wino<CIN, POOL>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        AXT_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GeoW::LDS_B));
+        attr_set = true;
+    }
+    AXT_REQUIRE(Hin % 16 == 0 && u != nullptr, "conv (winograd): map size %d not a multiple of the 16x16 tile, or weights not packed", Hin);
+    AXT_REQUIRE((double)CIN * Hin * Hin * 4 < 2.0e9, "conv (winograd): map too large");
+    const int nwork = (Hin / 16) * (Hin / 16) * B;
+    hipLaunchKernelGGL(kern, dim3(persistent_grid(nwork, 1)), dim3(512), GeoW::LDS_B, st, in, u, bias, out, Hin, B);
+    AXT_LAUNCH_CHECK();
+    return AXT_OK;
+}
+
 template <int CIN, int COUT, bool POOL, int CCH, int NT>
 int launch_conv(const float *in, const float *w, const float *bias, float *out, int Hin, int ngroups, int B,
                 hipStream_t st)
@@ -1304,7 +1593,8 @@ int run_front_a(axt_detector *d, const float *frames, int Hf, int Wf, int t0, in
     {
         ProfSpan ps(d, st, 2, nb);
         float *dst = d->d_act[2] + (size_t)slot0 * 80 * 64 * 64;
-        rc = d->arith ? launch_conv_b3<40, true>(d->d_act[1], d->d_wb3[2], d->d_bconv[2], dst, 128, nb, st)
+        rc = d->arith == 2 ? launch_conv_wino<40, true>(d->d_act[1], d->d_wwino[2], d->d_bconv[2], dst, 128, nb, st)
+             : d->arith ? launch_conv_b3<40, true>(d->d_act[1], d->d_wb3[2], d->d_bconv[2], dst, 128, nb, st)
                       : launch_conv<40, 80, true, 8, 5>(d->d_act[1], d->d_wconv[2], d->d_bconv[2], dst, 128, 1, nb, st);
         if (rc) return rc;
     }
@@ -1317,13 +1607,15 @@ int run_front_b(axt_detector *d, int nb, float *act4_out, hipStream_t st)
     int rc;
     {
         ProfSpan ps(d, st, 3, nb);
-        rc = d->arith ? launch_conv_b3<80, false>(d->d_act[2], d->d_wb3[3], d->d_bconv[3], d->d_act[3], 64, nb, st)
+        rc = d->arith == 2 ? launch_conv_wino<80, false>(d->d_act[2], d->d_wwino[3], d->d_bconv[3], d->d_act[3], 64, nb, st)
+             : d->arith ? launch_conv_b3<80, false>(d->d_act[2], d->d_wb3[3], d->d_bconv[3], d->d_act[3], 64, nb, st)
                       : launch_conv<80, 80, false, 8, 5>(d->d_act[2], d->d_wconv[3], d->d_bconv[3], d->d_act[3], 64, 1, nb, st);
         if (rc) return rc;
     }
     {
         ProfSpan ps(d, st, 4, nb);
-        rc = d->arith ? launch_conv_b3<80, true>(d->d_act[3], d->d_wb3[4], d->d_bconv[4], act4_out, 64, nb, st)
+        rc = d->arith == 2 ? launch_conv_wino<80, true>(d->d_act[3], d->d_wwino[4], d->d_bconv[4], act4_out, 64, nb, st)
+             : d->arith ? launch_conv_b3<80, true>(d->d_act[3], d->d_wb3[4], d->d_bconv[4], act4_out, 64, nb, st)
                       : launch_conv<80, 80, true, 8, 5>(d->d_act[3], d->d_wconv[4], d->d_bconv[4], act4_out, 64, 1, nb, st);
         if (rc) return rc;
     }
@@ -1336,13 +1628,15 @@ int run_back(axt_detector *d, int nb, float *d_yolo, hipStream_t st)
     int rc;
     {
         ProfSpan ps(d, st, 5, nb);
-        rc = d->arith ? launch_conv_b3<80, false>(d->d_act[4], d->d_wb3[5], d->d_bconv[5], d->d_act[5], 32, nb, st)
+        rc = d->arith == 2 ? launch_conv_wino<80, false>(d->d_act[4], d->d_wwino[5], d->d_bconv[5], d->d_act[5], 32, nb, st)
+             : d->arith ? launch_conv_b3<80, false>(d->d_act[4], d->d_wb3[5], d->d_bconv[5], d->d_act[5], 32, nb, st)
                       : launch_conv<80, 80, false, 8, 5>(d->d_act[4], d->d_wconv[5], d->d_bconv[5], d->d_act[5], 32, 1, nb, st);
         if (rc) return rc;
     }
     {
         ProfSpan ps(d, st, 6, nb);
-        rc = d->arith ? launch_conv_b3<80, true>(d->d_act[5], d->d_wb3[6], d->d_bconv[6], d->d_act[6], 32, nb, st)
+        rc = d->arith == 2 ? launch_conv_wino<80, true>(d->d_act[5], d->d_wwino[6], d->d_bconv[6], d->d_act[6], 32, nb, st)
+             : d->arith ? launch_conv_b3<80, true>(d->d_act[5], d->d_wb3[6], d->d_bconv[6], d->d_act[6], 32, nb, st)
                       : launch_conv<80, 80, true, 8, 5>(d->d_act[5], d->d_wconv[6], d->d_bconv[6], d->d_act[6], 32, 1, nb, st);
         if (rc) return rc;
     }
@@ -1473,7 +1767,7 @@ int axt_detector_create(const float *const *h_tensors, int n_tensors, int max_ba
 
 int axt_detector_set_arith(axt_detector *d, int mode)
 {
-    AXT_REQUIRE(d != nullptr && (mode == 0 || mode == 1), "axt_detector_set_arith: mode must be 0 (f32) or 1 (bf16x3)");
+    AXT_REQUIRE(d != nullptr && mode >= 0 && mode <= 2, "axt_detector_set_arith: mode must be 0 (direct f32), 1 (bf16x3) or 2 (f32 Winograd)");
     if (mode == 1 && !d->d_wb3[2]) {
         std::vector<uint16_t> pk;
         for (int li = 2; li <= 6; ++li) {
@@ -1481,6 +1775,15 @@ int axt_detector_set_arith(axt_detector *d, int mode)
             const int rc = dev_alloc(d, &d->d_wb3[li], pk.size() / 2);
             if (rc) return rc;
             AXT_CHECK_HIP(hipMemcpy(d->d_wb3[li], pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
+        }
+    }
+    if (mode == 2 && !d->d_wwino[2]) {
+        std::vector<float> pk;
+        for (int li = 2; li <= 6; ++li) {
+            pack_wino(kConv[li].cin, d->h_wfold[li], pk);
+            const int rc = dev_alloc(d, &d->d_wwino[li], pk.size());
+            if (rc) return rc;
+            AXT_CHECK_HIP(hipMemcpy(d->d_wwino[li], pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
         }
     }
     d->arith = mode;
@@ -1492,6 +1795,7 @@ void axt_detector_destroy(axt_detector *d)
     if (!d) return;
     for (int i = 0; i < 8; ++i) {
         (void)hipFree(d->d_wb3[i]);
+        (void)hipFree(d->d_wwino[i]);
         (void)hipFree(d->d_wconv[i]);
         (void)hipFree(d->d_bconv[i]);
         (void)hipFree(d->d_act[i]);

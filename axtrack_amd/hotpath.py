@@ -44,7 +44,7 @@ class Detector:
     """Device-resident YOLO_AXTrack (model.py:20-125) in eval mode; `detect_axons` keeps the
     reference's name and tensor contract (model.py:119-125)."""
 
-    ARITH = {'f32': 0, 'bf16x3': 1}
+    ARITH = {'f32': 0, 'bf16x3': 1, 'f32_winograd': 2}
 
     def __init__(self, state_dict, max_batch=256, device='cuda:0', arith='f32'):
         _require_gpu()

@@ -47,7 +47,7 @@ def main():
     ap.add_argument('--assoc', default='hungarian', choices=['hungarian', 'mcf'],
                     help="association of workload c3: 'hungarian' = BASELINE config 3 as written (frame-to-frame), "
                          "'mcf' = the reference's global min-cost-flow tracker")
-    ap.add_argument('--arith', default='f32', choices=['f32', 'bf16x3'],
+    ap.add_argument('--arith', default='f32', choices=['f32', 'bf16x3', 'f32_winograd'],
                     help="arithmetic of the stride-1 conv blocks: 'f32' (default, the headline: f32-in / f32-accumulate MFMA) or the "
                          "opt-in 'bf16x3' (three bf16 terms per operand on the bf16 matrix pipe, f32 accumulation): a SEPARATE line")
     ap.add_argument('--frames', type=int, default=256, help='input frames per GPU (T_all)')

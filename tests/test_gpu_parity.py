@@ -1375,6 +1375,36 @@ def test_cnn_bf16x3_arithmetic_against_oracle_and_f32_path(golden, weights):
         det.set_arith('fp8')
 
 
+def test_cnn_winograd_arithmetic_against_oracle_and_direct_path(golden, weights):
+    """parameters['CNN_ARITH'] = 'f32_winograd': the stride-1 conv blocks with 80 output channels as Winograd F(2x2,3x3) on the
+    f32 matrix pipe (all arithmetic f32). Same tolerance as the direct kernels against the reference's golden grids and the
+    oracle's f32 forward pass (zero padding of every layer, hot corner pixels, ragged frames, a batch that leaves
+    workgroups with unequal tile counts), and within 2e-5 of the direct kernels themselves."""
+    import axtrack_amd
+    det = axtrack_amd.Detector(weights, max_batch=24)
+    g = golden('cnn_512')
+    frames = dev(synth.synth_frames(int(g['T_all']), 512, 512, seed=int(g['frames_seed'])))
+    y32 = det.detect_frames(frames, [(0, 0)]).cpu().numpy()
+    det.set_arith('f32_winograd')
+    yw = det.detect_frames(frames, [(0, 0)]).cpu().numpy()
+    np.testing.assert_allclose(yw[:, 0], g['yolo'], atol=CNN_ATOL, rtol=CNN_RTOL)
+    assert np.abs(yw[:, 0] - g['yolo']).max() < 5e-5
+    assert not np.array_equal(yw, y32) and np.abs(yw - y32).max() < 2e-5
+    X = np.zeros((4, 5, 512, 512), np.float32)
+    X[1] = 1.0
+    for c, (yy, xx) in enumerate([(0, 0), (0, 511), (511, 0), (511, 511), (255, 256)]):
+        X[2, c, yy, xx] = 50.0
+    X[3] = synth.synth_frames(5, 512, 512, seed=9) * 3
+    np.testing.assert_allclose(det.detect_axons(dev(X)).cpu().numpy(), orc.cnn_forward(weights, X), atol=CNN_ATOL, rtol=CNN_RTOL)
+    fr = synth.synth_frames(6, 600, 1022, seed=3)                          # ragged, width not a multiple of 4
+    keep = hp.tile_occupancy(dev(fr))
+    y = det.detect_frames(dev(fr), keep).cpu().numpy()
+    for t in range(2):
+        np.testing.assert_allclose(y[t], orc.cnn_forward(weights, orc.frame_tile_stack(fr, t, keep)), atol=CNN_ATOL, rtol=CNN_RTOL)
+    det.set_arith('f32')
+    assert np.array_equal(det.detect_frames(frames, [(0, 0)]).cpu().numpy(), y32)
+
+
 def test_inference_with_bf16x3_parameter(weights):
     """The parameter is read at inference time (callers edit the dict between the steps, examples/test.py:19): the whole
     path with CNN_ARITH='bf16x3' -- detections and trajectories equal the oracle's given the grids the detector produced,
