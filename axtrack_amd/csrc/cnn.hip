@@ -545,7 +545,7 @@ __device__ __forceinline__ void wino_body(const float *__restrict__ in, const fl
     using G = GeoW;
     constexpr int NCH = CIN / G::CCH;
     constexpr int N0 = XFORM ? 0 : 2;              // first output-channel block of this wave
-    static_assert(CIN % G::CCH == 0, "CIN must be a multiple of 8");
+    static_assert(CIN % G::CCH == 0 && NCH >= 2, "CIN must be a multiple of 8, at least 16");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 15, q = lane >> 4;
     const int m = wave & 3;
     const int tiles_x = H >> 4, ntile = tiles_x * tiles_x;
@@ -559,76 +559,91 @@ __device__ __forceinline__ void wino_body(const float *__restrict__ in, const fl
 #pragma unroll
     for (int n = 0; n < NTW; ++n) bias_v[n] = bias[(N0 + n) * 16 + p];
 
-    // ---- loads of one chunk: raw patches (transform waves) + this wave's share of the U pieces ----
-    float d[2][4][4];
-    int voA[4], voB[4], voC[4];
+    // ---- raw patches (transform waves): fetched one chunk ahead of their use ----
+    // A patch row = [left][mid.x mid.y][right] at columns x0 + 2 tx - 1 .. + 2. Every lane loads only its aligned middle
+    // pair (8 lanes = 64 contiguous bytes per row and channel); left / right are the neighbouring lanes' pairs (DPP),
+    // except at the ends of the 16-pixel row, where one sparse load brings the halo column (zero outside the image).
+    // Rows outside the image take the out-of-range offset (zeros).
+    float d[1][2][4][3];                            // [set][k-step][row][mid.x, mid.y, halo]
+    int vo_mid[4], vo_halo[4];
     __amdgpu_buffer_rsrc_t ld_rsrc;
+    const bool first_col = (p & 7) == 0, last_col = (p & 7) == 7;
+    int lw = wr.begin, lc = 0;                      // load cursor: tile and chunk of the next patches to fetch
     auto plan_tile = [&](int w) {
         const int tile = w % ntile, b = w / ntile;
         ld_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in) + (long)b * CIN * cstride, 0, kBufRecords, 0x00020000);
-        if constexpr (XFORM) {
-            const int y0 = (tile / tiles_x) * 16, x0 = (tile % tiles_x) * 16;
-            const int ty = 2 * m + (p >> 3), tx = p & 7;
-            const int gx0 = x0 + 2 * tx - 1;
+        const int y0 = (tile / tiles_x) * 16, x0 = (tile % tiles_x) * 16;
+        const int ty = 2 * m + (p >> 3), tx = p & 7;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gy = y0 + 2 * ty - 1 + r;
+            const bool ok = gy >= 0 && gy < H;
+            const int rowb = q * cstride + gy * H;
+            vo_mid[r] = ok ? (rowb + x0 + 2 * tx) * 4 : (int)kOobOffset;
+            const int hx = first_col ? x0 - 1 : x0 + 16;
+            vo_halo[r] = (ok && (first_col || last_col) && hx >= 0 && hx < H) ? (rowb + hx) * 4 : (int)kOobOffset;
+        }
+    };
+    // patch row k of 8 (k-step, row) of the chunk at the load cursor -> set
+    auto raw_load = [&](int set, int k) {
+        const int s = k / 4, r = k % 4;
+        const int soff = (lc * G::CCH + s * 4) * cstride * 4;
+        const f32x2 mid = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(ld_rsrc, vo_mid[r], soff, 0));
+        d[set][s][r][0] = mid.x;
+        d[set][s][r][1] = mid.y;
+        d[set][s][r][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ld_rsrc, vo_halo[r], soff, 0));
+    };
+    // the cursor moves on by one chunk; past the last chunk of the last tile it stays (that chunk is fetched again, unused)
+    auto advance_cursor = [&]() {
+        if (lc + 1 < NCH) ++lc;
+        else if (lw + wr.step < wr.end) {
+            lw += wr.step;
+            lc = 0;
+            plan_tile(lw);
+        }
+    };
+    // DMA piece k of this wave's 5 of U chunk c
+    auto dma_piece = [&](int c, int buf, int k) {
+        const float *src = upk + (long)c * G::UBUF + (wave * 5 + k) * 256 + lane * 4;
+        float *dst = Us + buf * G::UBUF + (wave * 5 + k) * 256;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    };
+    // B^T d B of the two patches in `set` -> V[buf][pos][m][lane][k-step]
+    auto xform_store = [&](int set, int buf) {
+        float v[2][16];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float row[4][4], t[4][4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int gy = y0 + 2 * ty - 1 + r;
-                const bool ok = gy >= 0 && gy < H;
-                const int base = (q * cstride + gy * H + gx0) * 4;
-                voA[r] = (ok && gx0 >= 0) ? base : (int)kOobOffset;
-                voB[r] = ok ? base + 4 : (int)kOobOffset;
-                voC[r] = (ok && gx0 + 3 < H) ? base + 12 : (int)kOobOffset;
+                const float halo = d[set][s][r][2];
+                const int xi = __builtin_bit_cast(int, d[set][s][r][0]), yi = __builtin_bit_cast(int, d[set][s][r][1]);
+                const float left = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, yi, 0x111, 0xf, 0xf, false));    // row_shr:1
+                const float right = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, xi, 0x101, 0xf, 0xf, false));   // row_shl:1
+                row[r][0] = first_col ? halo : left;
+                row[r][1] = d[set][s][r][0];
+                row[r][2] = d[set][s][r][1];
+                row[r][3] = last_col ? halo : right;
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                t[0][x] = row[0][x] - row[2][x];
+                t[1][x] = row[1][x] + row[2][x];
+                t[2][x] = row[2][x] - row[1][x];
+                t[3][x] = row[1][x] - row[3][x];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[s][i * 4 + 0] = t[i][0] - t[i][2];
+                v[s][i * 4 + 1] = t[i][1] + t[i][2];
+                v[s][i * 4 + 2] = t[i][2] - t[i][1];
+                v[s][i * 4 + 3] = t[i][1] - t[i][3];
             }
         }
-    };
-    auto issue = [&](int c, int buf) {
-        if constexpr (XFORM) {
+        float *dstv = Vs + buf * G::VBUF + (m * 64 + lane) * 2;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int soff = (c * G::CCH + s * 4) * cstride * 4;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    d[s][r][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ld_rsrc, voA[r], soff, 0));
-                    const f32x2 mid = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(ld_rsrc, voB[r], soff, 0));
-                    d[s][r][1] = mid.x;
-                    d[s][r][2] = mid.y;
-                    d[s][r][3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ld_rsrc, voC[r], soff, 0));
-                }
-            }
-        }
-        const float *src = upk + (long)c * G::UBUF + (wave * 5) * 256 + lane * 4;
-        float *dst = Us + buf * G::UBUF + (wave * 5) * 256;
-#pragma unroll
-        for (int k = 0; k < 5; ++k)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + k * 256),
-                                             (__attribute__((address_space(3))) void *)(dst + k * 256), 16, 0, 0);
-    };
-    // B^T d B of the two patches of this lane -> V[buf][pos][m][lane][s]
-    auto xform_store = [&](int buf) {
-        if constexpr (XFORM) {
-            float v[2][16];
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                float t[4][4];
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    t[0][x] = d[s][0][x] - d[s][2][x];
-                    t[1][x] = d[s][1][x] + d[s][2][x];
-                    t[2][x] = d[s][2][x] - d[s][1][x];
-                    t[3][x] = d[s][1][x] - d[s][3][x];
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v[s][i * 4 + 0] = t[i][0] - t[i][2];
-                    v[s][i * 4 + 1] = t[i][1] + t[i][2];
-                    v[s][i * 4 + 2] = t[i][2] - t[i][1];
-                    v[s][i * 4 + 3] = t[i][1] - t[i][3];
-                }
-            }
-            float *dstv = Vs + buf * G::VBUF + (m * 64 + lane) * 2;
-#pragma unroll
-            for (int pos = 0; pos < 16; ++pos) *reinterpret_cast<f32x2 *>(dstv + pos * 512) = f32x2{v[0][pos], v[1][pos]};
-        }
+        for (int pos = 0; pos < 16; ++pos) *reinterpret_cast<f32x2 *>(dstv + pos * 512) = f32x2{v[0][pos], v[1][pos]};
     };
 
     f32x4 acc[16][NTW];
@@ -638,7 +653,11 @@ __device__ __forceinline__ void wino_body(const float *__restrict__ in, const fl
 #pragma unroll
             for (int n = 0; n < NTW; ++n) acc[pos][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
-    auto mfma_chunk = [&](int buf) {
+    // The MFMAs of the chunk in buffer `buf`. Behind the MFMAs of a position one slice of the loads is issued (in one
+    // block at the top of the chunk they would hold the wave, and with it half of the SIMD's MFMA supply, for their whole
+    // issue time): the DMA pieces of the next chunk's U into the other buffer, then (transform waves) the raw patches at
+    // the load cursor into register set `set`.
+    auto mfma_chunk = [&](int buf, int set, int c_next) {
         const float *va = Vs + buf * G::VBUF + (m * 64 + lane) * 2;
         const float *ub = Us + buf * G::UBUF + (N0 * 64 + lane) * 2;
         f32x2 a[2], bq[2][NTW];
@@ -659,8 +678,24 @@ __device__ __forceinline__ void wino_body(const float *__restrict__ in, const fl
 #pragma unroll
                 for (int n = 0; n < NTW; ++n)
                     acc[pos][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[slot][s], bq[slot][n][s], acc[pos][n], 0, 0, 0);
+            int nvm = 0;
+            if constexpr (XFORM) {
+                if (pos < 4) {                      // the patches first: they come from HBM
+                    raw_load(set, pos * 2);
+                    raw_load(set, pos * 2 + 1);
+                    nvm = 4;
+                } else if (pos < 9) {
+                    dma_piece(c_next, buf ^ 1, pos - 4);
+                    nvm = 1;
+                }
+            } else if (pos < 5) {
+                dma_piece(c_next, buf ^ 1, pos);
+                nvm = 1;
+            }
             __builtin_amdgcn_sched_group_barrier(0x100, 1 + NTW, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 2 * NTW, 0);
+            if (nvm == 4) __builtin_amdgcn_sched_group_barrier(0x010, 4, 0);
+            else if (nvm == 1) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
         }
     };
     // A^T M A, bias, LeakyReLU(0.1) (+ 2x2 max) and the stores of tile w
@@ -712,36 +747,51 @@ __device__ __forceinline__ void wino_body(const float *__restrict__ in, const fl
         }
     };
 
-    int w_cur = wr.begin, g = 0;
-    plan_tile(w_cur);
-    issue(0, 0);
+    // ---- prologue: patches and U of the first chunk; V of the first chunk ----
+    if constexpr (XFORM) {
+        plan_tile(lw);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) raw_load(0, k);
+        advance_cursor();
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) dma_piece(0, 0, k);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    xform_store(0);
+    if constexpr (XFORM) xform_store(0, 0);
     __syncthreads();
     zero_acc();
-    for (;;) {
-        const int w_next = w_cur + wr.step;
-        const bool more = w_next < wr.end;
-        for (int c = 0; c < NCH; ++c, ++g) {
-            const int buf = g & 1;
-            const bool last = c + 1 == NCH;
-            if (!last) issue(c + 1, buf ^ 1);
-            else if (more) {
-                plan_tile(w_next);
-                issue(0, buf ^ 1);
-            }
-            mfma_chunk(buf);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the raw patches and this wave's DMA pieces have landed
-            if (!last || more) xform_store(buf ^ 1);
-            if (last) {
-                epilogue(w_cur);
-                zero_acc();
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    // ---- the chunk stream (LDS buffer = parity of the chunk count) ----
+    int w_cur = wr.begin, c = 0;
+    bool done = false;
+    auto step = [&](int PAR) {
+        const bool last = c + 1 == NCH;
+        const int c_next = last ? 0 : c + 1;                       // U of the chunk after this one (any tile: same weights)
+        mfma_chunk(PAR, 0, c_next);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the patches and this wave's DMA pieces have landed
+        if constexpr (XFORM) {
+            advance_cursor();
+            // the transform reads d only from here on: without this tie the compiler starts it inside the MFMA stream and
+            // waits there for loads it has just issued
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    asm volatile("" : "+v"(d[0][s][r][0]), "+v"(d[0][s][r][1]), "+v"(d[0][s][r][2]));
+            xform_store(0, PAR ^ 1);                                // (after the WG's last chunk: of refetched patches, unused)
         }
-        if (!more) break;
-        w_cur = w_next;
-    }
+        if (last) {
+            epilogue(w_cur);
+            zero_acc();
+            c = 0;
+            w_cur += wr.step;
+            done = w_cur >= wr.end;
+        } else ++c;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    int g = 0;
+    do step(g++ & 1);
+    while (!done);
 }
 
 template <int CIN, bool POOL>

@@ -8,6 +8,9 @@ def short(name):
     m = re.search(r'conv3x3_bf16x3<(\d+), (true|false)', name)
     if m:
         return f'conv3x3_bf16x3<{m.group(1)}->80,s1{",pool" if m.group(2) == "true" else ""}>'
+    m = re.search(r'conv3x3_wino<(\d+), (true|false)', name)
+    if m:
+        return f'conv3x3_wino<{m.group(1)}->80,s1{",pool" if m.group(2) == "true" else ""}>'
     m = re.search(r'conv3x3_s2_k1<(\d+), (\d+)', name)
     if m:
         return f'conv<{m.group(1)}->{m.group(2)},s2>'
