@@ -1311,7 +1311,7 @@ struct axt_detector {
     unsigned *d_wb3[8] = {};    // conv blocks 2..6 packed for conv3x3_bf16x3 (allocated on the first switch to that arithmetic)
     std::vector<float> h_wfold[8];   // their BN-folded f32 weights [cout][cin][3][3], kept on the host for that packing
     float *d_wwino[8] = {};     // conv blocks 2..6 packed for conv3x3_wino (allocated on the first switch to that arithmetic)
-    int arith = 0;              // 0: direct f32 MFMA everywhere | 1: bf16x3 | 2: f32 Winograd F(2x2,3x3), for the stride-1 blocks with 80 output channels
+    int arith = 0;              // stride-1 blocks with 80 output channels: 0 direct f32 MFMA | 1 bf16x3 | 2 f32 Winograd F(2x2,3x3) (set by create)
     float *d_bconv[8] = {};     // folded bias
     float *d_wfc[3] = {};       // [K][Npad]
     float *d_bfc[3] = {};
@@ -1807,6 +1807,7 @@ int axt_detector_create(const float *const *h_tensors, int n_tensors, int max_ba
         axt_set_error("device synchronize failed after upload");
         rc = AXT_EHIP;
     }
+    if (!rc) rc = axt_detector_set_arith(d, 2);        // default arithmetic: f32 Winograd for the stride-1 blocks
     if (rc) {
         axt_detector_destroy(d);
         return rc;

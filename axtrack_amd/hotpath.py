@@ -44,7 +44,7 @@ class Detector:
     """Device-resident YOLO_AXTrack (model.py:20-125) in eval mode; `detect_axons` keeps the
     reference's name and tensor contract (model.py:119-125)."""
 
-    ARITH = {'f32': 0, 'bf16x3': 1, 'f32_winograd': 2}
+    ARITH = {'f32': 2, 'f32_winograd': 2, 'f32_direct': 0, 'bf16x3': 1}
 
     def __init__(self, state_dict, max_batch=256, device='cuda:0', arith='f32'):
         _require_gpu()
@@ -65,19 +65,20 @@ class Detector:
                        'axt_detector_create')
         self._h = handle
         self._lib = lib
-        self.arith = 'f32'
+        self.arith = 'f32'              # axt_detector_create leaves the handle in its default mode (f32 Winograd)
         self.set_arith(arith)
 
     def set_arith(self, arith):
-        """Arithmetic of the stride-1 conv blocks with 80 output channels: 'f32' (default: f32-in / f32-accumulate MFMA) or
-        'bf16x3' (opt-in: operands split into three bf16 terms, six partial products on the bf16 matrix pipe, f32
-        accumulation; parameters['CNN_ARITH']). See axt_detector_set_arith."""
+        """Arithmetic of the stride-1 conv blocks with 80 output channels (parameters['CNN_ARITH']): 'f32' (default; the
+        same as 'f32_winograd': Winograd F(2x2,3x3) on the f32 matrix pipe, every operation f32), 'f32_direct' (direct
+        convolution on the f32 matrix pipe: a k-ordered chain of f32 FMAs) or 'bf16x3' (opt-in: operands split into three
+        bf16 terms, six partial products on the bf16 matrix pipe, f32 accumulation). See axt_detector_set_arith."""
         if arith not in self.ARITH:
             raise ValueError(f"CNN_ARITH must be one of {sorted(self.ARITH)}, got {arith!r}")
-        if arith != self.arith:
+        if self.ARITH[arith] != self.ARITH[self.arith]:
             with torch.cuda.device(self.device):
                 _lib.check(self._lib.axt_detector_set_arith(self._h, self.ARITH[arith]), 'axt_detector_set_arith')
-            self.arith = arith
+        self.arith = arith
 
     def __del__(self):
         h, self._h = getattr(self, '_h', None), None

@@ -47,9 +47,11 @@ def main():
     ap.add_argument('--assoc', default='hungarian', choices=['hungarian', 'mcf'],
                     help="association of workload c3: 'hungarian' = BASELINE config 3 as written (frame-to-frame), "
                          "'mcf' = the reference's global min-cost-flow tracker")
-    ap.add_argument('--arith', default='f32', choices=['f32', 'bf16x3', 'f32_winograd'],
-                    help="arithmetic of the stride-1 conv blocks: 'f32' (default, the headline: f32-in / f32-accumulate MFMA) or the "
-                         "opt-in 'bf16x3' (three bf16 terms per operand on the bf16 matrix pipe, f32 accumulation): a SEPARATE line")
+    ap.add_argument('--arith', default='f32', choices=['f32', 'f32_winograd', 'f32_direct', 'bf16x3'],
+                    help="arithmetic of the stride-1 conv blocks: 'f32' (default, the headline; = 'f32_winograd': Winograd "
+                         "F(2x2,3x3) on the f32 matrix pipe, every operation f32), 'f32_direct' (direct convolution on the f32 "
+                         "matrix pipe) or the opt-in 'bf16x3' (three bf16 terms per operand on the bf16 matrix pipe, f32 "
+                         "accumulation): SEPARATE lines")
     ap.add_argument('--frames', type=int, default=256, help='input frames per GPU (T_all)')
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--cpu-frames', type=int, default=252, help='detection frames of the CPU-baseline sample (0 = skip)')
@@ -93,6 +95,8 @@ def main():
     P['DEVICE'] = str(dev)
     P['ASSOCIATION'] = args.assoc
     P['CNN_ARITH'] = args.arith
+    winograd = args.arith in ('f32', 'f32_winograd')
+    wino_blocks = ('conv2', 'conv4', 'conv5', 'conv7', 'conv8')          # the stride-1 blocks with 80 output channels
     n_tiles = (-(-H // 512)) * (-(-W // 512))
     model = axtrack_amd.Detector(sd, max_batch=min(per_rank * n_tiles, 1024), device=dev)
     tl = axtrack_amd.Timelapse(frames, name='bench', device=dev)
@@ -177,6 +181,26 @@ def main():
         same_on_all_ranks = bool(lo.item() == hi.item())
         assert same_on_all_ranks, 'ranks disagree on the trajectories of the gathered timelapse'
 
+    # the direct-convolution f32 kernels on the same workload, measured in the same run (after the timed region)
+    direct = None
+    if winograd and world == 1:
+        Pd = dict(P, CNN_ARITH='f32_direct')
+        def step_direct():
+            a = axtrack_amd.AxonDetections(model, tl, Pd, None)
+            a.detect_dataset(cache=None)
+            if args.workload == 'c3':
+                a.assign_ids(None, None)
+        step_direct()
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        for _ in range(3):
+            step_direct()
+        torch.cuda.synchronize(dev)
+        dtd = (time.perf_counter() - t) / 3
+        direct = {'cnn_arith': 'f32_direct', 'value': round(total_frames / dtd, 2), 'unit': 'frames/s',
+                  'ms_per_step': round(dtd * 1e3, 3), 'steps': 3}
+        model.set_arith(args.arith)
+
     # the other association variant, measured in the same run (untimed region, one step) for transparency
     other = None
     if args.workload == 'c3' and world == 1:
@@ -199,7 +223,7 @@ def main():
             'value': round(value, 2), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': 'f32' if args.arith == 'f32' else 'f32 via 3 x bf16 split operands (6 partial products, f32 accumulate) in conv blocks 2-8; f32 elsewhere',
+            'dtype': 'f32' if args.arith != 'bf16x3' else 'f32 via 3 x bf16 split operands (6 partial products, f32 accumulate) in conv blocks 2-8; f32 elsewhere',
             'data': 'synthetic',
             'config': {'workload': f'{args.workload}: synthetic {H}x{W}x{args.frames} grayscale timelapse per GPU, '
                                    + (f'detection + path-cost matrix + {"Hungarian (frame-to-frame)" if args.assoc == "hungarian" else "global min-cost-flow"} association (IDed_dets_all)'
@@ -207,7 +231,9 @@ def main():
                        'association': args.assoc if args.workload == 'c3' else None,
                        'detection_frames_per_gpu': per_rank, 'tiles_per_frame': n_tiles,
                        'weights': 'random-init (synth seed 42)', 'parallelism': f'frame-sharded x{world}',
-                       'cnn_arith': args.arith},
+                       'cnn_arith': args.arith,
+                       'conv_algorithm': ('Winograd F(2x2,3x3), f32, for conv blocks 2,4,5,7,8 (stride 1, 80 output channels); direct elsewhere'
+                                          if winograd else 'direct')},
             'stages': stages,
             'detections': int(ad._host_dets()[0].sum()),
         }
@@ -223,27 +249,38 @@ def main():
             out['n_ids'] = getattr(ad, 'n_ids', None)
             if other:
                 out['other_association_variant'] = other
+        if direct:
+            out['other_arithmetic_variant'] = direct
         if prof:
+            # FLOPs a kernel EXECUTES on the matrix pipe: a Winograd block multiplies 16 times per 2x2 output tile, input and
+            # output channel where the direct convolution multiplies 36 times (its transforms are additions on the vector pipe)
+            def executed(k):
+                return k['flops_per_tile'] * k['tiles'] * (16.0 / 36.0 if winograd and k['name'].split()[0] in wino_blocks else 1.0)
             dom = prof[dom_idx]                                   # bracketed inside the timed region
-            flops = dom['flops_per_tile'] * dom['tiles']
+            flops = executed(dom)
             achieved = flops / (dom['ms'] * 1e-3) / 1e12
             cnn_ms = sum(k['ms'] for k in table)                  # one untimed pass, all launches bracketed
-            cnn_flops = sum(k['flops_per_tile'] * k['tiles'] for k in table if 'reduce' not in k['name'])
+            cnn_flops = sum(executed(k) for k in table if 'reduce' not in k['name'])
+            cnn_flops_direct = sum(k['flops_per_tile'] * k['tiles'] for k in table if 'reduce' not in k['name'])
             peak = PEAK_F32_MFMA_TFLOPS
             if args.arith == 'bf16x3' and dom['name'].split()[0] in ('conv2', 'conv4', 'conv5', 'conv7', 'conv8'):
                 peak = PEAK_BF16_MFMA_TFLOPS / 6.0      # algorithmic f32 multiply-adds cost six bf16 products each
             out['roofline'] = {
                 'bound': 'mfma', 'kernel': dom['name'], 'achieved': round(achieved, 2), 'peak': round(peak, 1),
-                'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), **committed_traffic(dom['name']),
+                'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), **committed_traffic(dom['name'], winograd and dom['name'].split()[0] in wino_blocks),
                 'avg_launch_ms': round(dom['ms'] / max(dom['launches'], 1), 4),
                 'flops_per_launch': flops / max(dom['launches'], 1),
+                'flops': ('executed on the matrix pipe (Winograd: 16/36 of the direct convolution\'s); '
+                          'direct_equivalent = the same launches priced as direct convolutions' if winograd else 'direct convolution'),
+                'direct_equivalent': round(dom['flops_per_tile'] * dom['tiles'] / (dom['ms'] * 1e-3) / 1e12, 2),
                 'measured': 'HIP events around every launch of this kernel inside the timed region',
                 'whole_cnn': {'achieved': round(cnn_flops / (cnn_ms * 1e-3) / 1e12, 2),
                               'frac': round(cnn_flops / (cnn_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                              'direct_equivalent': round(cnn_flops_direct / (cnn_ms * 1e-3) / 1e12, 2),
                               'ms_per_step': round(cnn_ms, 3),
                               'measured': 'one untimed pass with every launch bracketed'},
                 'kernels': [{'name': k['name'], 'ms_per_step': round(k['ms'], 4),
-                             'tflops': round(k['flops_per_tile'] * k['tiles'] / max(k['ms'], 1e-9) / 1e9, 2)}
+                             'tflops': round(executed(k) / max(k['ms'], 1e-9) / 1e9, 2)}
                             for k in table],
             }
         if world == 1 and args.cpu_frames > 0:
@@ -301,7 +338,7 @@ def verify(args, ad, frames_host, sd, per_rank, world):
                        'seconds': round(time.perf_counter() - t0, 1)}}
 
 
-def committed_traffic(kernel_name):
+def committed_traffic(kernel_name, wino=False):
     """roofline.traffic: HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
     same command (profiles/*_traffic.json, written by profiles/summarize.py; the newest that matches the kernel), or
     None if there is none."""
@@ -311,7 +348,7 @@ def committed_traffic(kernel_name):
     for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_traffic.json'))):
         t = json.load(open(f))
         m = re.search(r'<(\d+)->(\d+)', t.get('kernel', ''))
-        if m and f'{m.group(1)}>{m.group(2)}' in kernel_name.replace(' ', ''):
+        if m and f'{m.group(1)}>{m.group(2)}' in kernel_name.replace(' ', '') and ('wino' in t.get('kernel', '')) == bool(wino):
             best = t
     if best is None:
         return {'traffic': None}

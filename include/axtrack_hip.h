@@ -63,11 +63,16 @@ int axt_detector_create(const float *const *h_tensors, int n_tensors, int max_ba
 void axt_detector_destroy(axt_detector *det);
 
 /* Arithmetic of the stride-1 conv blocks with 80 output channels (blocks 2, 4, 5, 7, 8 of model.py:85-103; 71 % of the
- * forward pass's FLOPs). mode 0 (default): f32-in / f32-accumulate MFMA, a k-ordered chain of exact f32 FMAs like the
- * reference's f32 convolution. mode 1 ("bf16x3", opt-in, parameters['CNN_ARITH']): every f32 operand split exactly into
- * three bf16 terms, six partial products per multiply on the bf16 matrix pipe, f32 accumulation -- per-product error of
- * the size of an f32 rounding, a faster forward pass; not bit-identical to mode 0. The packed bf16
- * weights are built on the first switch to mode 1. Synchronous. */
+ * forward pass's FLOPs); parameters['CNN_ARITH'].
+ * mode 2 (default after axt_detector_create, "f32" / "f32_winograd"): Winograd F(2x2,3x3) on the f32 matrix pipe -- every
+ *   operation f32 (transforms are additions, G g G^T formed in f64 and rounded once), 16/36 of the direct multiplications;
+ *   as close to an f64 convolution as the direct kernel, like the algorithms cuDNN / oneDNN choose for
+ *   the reference's own Conv2d.
+ * mode 0 ("f32_direct"): direct convolution, f32-in / f32-accumulate MFMA, a k-ordered chain of f32 FMAs per output.
+ * mode 1 ("bf16x3", opt-in): every f32 operand split exactly into three bf16 terms, six partial products per multiply on
+ *   the bf16 matrix pipe, f32 accumulation -- per-product error of the size of an f32 rounding.
+ * The modes agree to ~1e-6 on the grids and are not bit-identical to each other. Packed weights of modes 1 and 2 are built
+ * on the first switch to them. Synchronous. */
 int axt_detector_set_arith(axt_detector *det, int mode);
 /* bytes of device memory held by the handle (packed weights + activation workspace) */
 size_t axt_detector_device_bytes(const axt_detector *det);

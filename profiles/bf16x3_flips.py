@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Characterises the opt-in CNN_ARITH='bf16x3' arithmetic on BASELINE config 3 (512x512x256, 252 detection frames):
-max |yolo - oracle| on sampled frames for both arithmetics, max |bf16x3 - f32| over all grids, and how many detections
-differ after decode / 0.55 cut / NMS (anchors moved by a rounding tie, confidences crossing the floor).
-    python profiles/bf16x3_flips.py            (on the GPU box)"""
+"""Characterises one CNN_ARITH arithmetic against another on BASELINE config 3 (512x512x256, 252 detection frames):
+max |yolo - oracle| on sampled frames for both, max |B - A| over all grids, and how many detections differ after
+decode / 0.55 cut / NMS (anchors moved by a rounding tie, confidences crossing the floor).
+    python profiles/bf16x3_flips.py [A B]      (on the GPU box; default: f32_direct bf16x3; the keys keep the names
+                                                 f32 / bf16x3 of the first study: f32 = A, bf16x3 = B)"""
 import json, os, sys
 import numpy as np
 import torch
@@ -17,13 +18,14 @@ sd = synth.synth_state_dict(42)
 model = axtrack_amd.Detector(sd, max_batch=252)
 tl = axtrack_amd.Timelapse(frames, name='c3')
 res = {}
-for arith in ('f32', 'bf16x3'):
-    P = dict(params.load_parameters(), ASSOCIATION='hungarian', CNN_ARITH=arith)
+A, Bn = (sys.argv[1], sys.argv[2]) if len(sys.argv) > 2 else ('f32_direct', 'bf16x3')
+for arith, name in (('f32', A), ('bf16x3', Bn)):
+    P = dict(params.load_parameters(), ASSOCIATION='hungarian', CNN_ARITH=name)
     ad = axtrack_amd.inference(tl, model, None, P, None, None, None)
     res[arith] = (ad._yolo.cpu().numpy(), ad._host_dets(), ad.n_ids)
 sample = [0, 1, 63, 126, 127, 128, 200, 251]
 ref = np.stack([orc.cnn_forward(sd, orc.frame_tile_stack(frames, t, [(0, 0)])) for t in sample])
-out = {'frames': 252, 'oracle_sample': sample}
+out = {'frames': 252, 'oracle_sample': sample, 'A (keys f32)': A, 'B (keys bf16x3)': Bn}
 for arith in res:
     out[f'max_abs_err_vs_oracle_{arith}'] = float(np.abs(res[arith][0][sample] - ref).max())
 y32, yb = res['f32'][0], res['bf16x3'][0]

@@ -1346,7 +1346,7 @@ def test_cnn_bf16x3_arithmetic_against_oracle_and_f32_path(golden, weights):
     """parameters['CNN_ARITH'] = 'bf16x3': the stride-1 conv blocks with 80 output channels on the bf16 matrix pipe (three
     bf16 terms per f32 operand, six partial products, f32 accumulation). Same tolerance as the f32 kernels against the
     reference's golden grids and the oracle's f32 forward pass (edge inputs: zero padding of every layer, hot corner
-    pixels, a frame width that is not a multiple of 4), and within 2e-5 of the f32 kernels themselves; switching back
+    pixels, a frame width that is not a multiple of 4), and within 2e-5 of the default f32 arithmetic; switching back
     restores the f32 results bit for bit."""
     import axtrack_amd
     det = axtrack_amd.Detector(weights, max_batch=24)
@@ -1375,34 +1375,62 @@ def test_cnn_bf16x3_arithmetic_against_oracle_and_f32_path(golden, weights):
         det.set_arith('fp8')
 
 
-def test_cnn_winograd_arithmetic_against_oracle_and_direct_path(golden, weights):
-    """parameters['CNN_ARITH'] = 'f32_winograd': the stride-1 conv blocks with 80 output channels as Winograd F(2x2,3x3) on the
-    f32 matrix pipe (all arithmetic f32). Same tolerance as the direct kernels against the reference's golden grids and the
-    oracle's f32 forward pass (zero padding of every layer, hot corner pixels, ragged frames, a batch that leaves
-    workgroups with unequal tile counts), and within 2e-5 of the direct kernels themselves."""
+def test_cnn_winograd_and_direct_arithmetic_against_oracle(golden, weights):
+    """parameters['CNN_ARITH']: 'f32' (the default, = 'f32_winograd': the stride-1 conv blocks with 80 output channels as
+    Winograd F(2x2,3x3) on the f32 matrix pipe, all arithmetic f32) and 'f32_direct' (direct convolution on the f32 matrix
+    pipe). Both within the same tolerance of the reference's golden grids and of the oracle's f32 forward pass (zero padding
+    of every layer, hot corner pixels, ragged frames whose width is not a multiple of 4, a batch that leaves the persistent
+    workgroups with unequal tile counts), within 2e-5 of each other, and switching back and forth restores each bit for
+    bit."""
     import axtrack_amd
     det = axtrack_amd.Detector(weights, max_batch=24)
+    assert det.arith == 'f32'
     g = golden('cnn_512')
     frames = dev(synth.synth_frames(int(g['T_all']), 512, 512, seed=int(g['frames_seed'])))
-    y32 = det.detect_frames(frames, [(0, 0)]).cpu().numpy()
-    det.set_arith('f32_winograd')
-    yw = det.detect_frames(frames, [(0, 0)]).cpu().numpy()
-    np.testing.assert_allclose(yw[:, 0], g['yolo'], atol=CNN_ATOL, rtol=CNN_RTOL)
-    assert np.abs(yw[:, 0] - g['yolo']).max() < 5e-5
-    assert not np.array_equal(yw, y32) and np.abs(yw - y32).max() < 2e-5
     X = np.zeros((4, 5, 512, 512), np.float32)
     X[1] = 1.0
     for c, (yy, xx) in enumerate([(0, 0), (0, 511), (511, 0), (511, 511), (255, 256)]):
         X[2, c, yy, xx] = 50.0
     X[3] = synth.synth_frames(5, 512, 512, seed=9) * 3
-    np.testing.assert_allclose(det.detect_axons(dev(X)).cpu().numpy(), orc.cnn_forward(weights, X), atol=CNN_ATOL, rtol=CNN_RTOL)
+    ref_X = orc.cnn_forward(weights, X)
     fr = synth.synth_frames(6, 600, 1022, seed=3)                          # ragged, width not a multiple of 4
     keep = hp.tile_occupancy(dev(fr))
-    y = det.detect_frames(dev(fr), keep).cpu().numpy()
-    for t in range(2):
-        np.testing.assert_allclose(y[t], orc.cnn_forward(weights, orc.frame_tile_stack(fr, t, keep)), atol=CNN_ATOL, rtol=CNN_RTOL)
-    det.set_arith('f32')
-    assert np.array_equal(det.detect_frames(frames, [(0, 0)]).cpu().numpy(), y32)
+    ref_fr = [orc.cnn_forward(weights, orc.frame_tile_stack(fr, t, keep)) for t in range(2)]
+    grids = {}
+    for arith in ('f32_winograd', 'f32_direct', 'f32'):
+        det.set_arith(arith)
+        y = det.detect_frames(frames, [(0, 0)]).cpu().numpy()
+        np.testing.assert_allclose(y[:, 0], g['yolo'], atol=CNN_ATOL, rtol=CNN_RTOL)
+        assert np.abs(y[:, 0] - g['yolo']).max() < 5e-5
+        grids[arith] = y
+        if arith == 'f32':
+            break
+        np.testing.assert_allclose(det.detect_axons(dev(X)).cpu().numpy(), ref_X, atol=CNN_ATOL, rtol=CNN_RTOL)
+        yr = det.detect_frames(dev(fr), keep).cpu().numpy()
+        for t in range(2):
+            np.testing.assert_allclose(yr[t], ref_fr[t], atol=CNN_ATOL, rtol=CNN_RTOL)
+    assert np.array_equal(grids['f32'], grids['f32_winograd'])
+    assert not np.array_equal(grids['f32_direct'], grids['f32_winograd'])
+    assert np.abs(grids['f32_direct'] - grids['f32_winograd']).max() < 2e-5
+    det.set_arith('f32_direct')
+    assert np.array_equal(det.detect_frames(frames, [(0, 0)]).cpu().numpy(), grids['f32_direct'])
+
+
+def test_inference_with_direct_convolution_parameter(weights):
+    """CNN_ARITH='f32_direct' through the whole path (the suite's other tests run the default arithmetic): detections and
+    trajectories equal the oracle's given the grids the detector produced, grids within tolerance of the oracle's."""
+    import axtrack_amd
+    frames = synth.synth_frames(12, 512, 512, seed=23)
+    model = axtrack_amd.Detector(weights, max_batch=8)
+    P = dict(params.load_parameters(), CNN_ARITH='f32_direct', MCF_MIN_FLOW=1)
+    ad = axtrack_amd.inference(axtrack_amd.Timelapse(frames, name='synth'), model, None, P, None, None, None)
+    assert model.arith == 'f32_direct'
+    yolo = ad._yolo.cpu().numpy()
+    for t in (0, 7):
+        np.testing.assert_allclose(yolo[t], orc.cnn_forward(weights, orc.frame_tile_stack(frames, t, ad.tile_yx)), atol=CNN_ATOL, rtol=CNN_RTOL)
+    ref = orc.inference(frames, weights, P=dict(orc.DEFAULTS, MCF_MIN_FLOW=1), yolo=list(yolo))
+    _assert_dets_equal_oracle(ad, ref['dets'])
+    assert tracks_from_next(np.zeros(len(ad._track_flat)), ad._track_flat, ad._offs) == ref['trajs']
 
 
 def test_inference_with_bf16x3_parameter(weights):
