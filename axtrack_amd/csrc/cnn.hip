@@ -10,6 +10,9 @@
 //                    traffic through buffer loads / stores (zero padding from the range check). Block 0 reads the
 //                    5-frame temporal stack straight from the timelapse (fuses Timelapse.get_frametiles_stack,
 //                    Timelapse.py:111-125,150-157).
+//   conv3x3_wino     the same stride-1 blocks with 80 output channels as Winograd F(2x2,3x3) on the same f32 MFMA: 16/36 of
+//                    the multiplications, every operation f32 -- the DEFAULT for conv blocks 2,4,5,7,8 (conv3x3_mfma stays
+//                    selectable: axt_detector_set_arith; conv block 10 always runs on it).
 //   gemm_mfma        split-K GEMM for the three linear layers, partial slabs reduced in a fixed order
 //                    (bit-reproducible) by reduce_bias_act (+ Sigmoid).
 //
@@ -524,10 +527,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3(
 //     V [pos 16][row block 4][lane 64][k-step 2]   (32 KB)   and   U [pos 16][channel block 5][lane 64][k-step 2]   (40 KB):
 //   lane-linear 8-byte elements, one conflict-free ds_read_b64 (256 B/clk) fetches a lane's operand for both k-steps.
 //   U is packed in exactly that order (pack_wino), so a chunk is 40 LDS-DMA pieces of 1 KiB (global_load_lds_dwordx4), five
-//   per wave, no registers and no ds_write. One barrier per chunk: at its top the loads of chunk g + 1 are issued (raw 4 x 4
-//   input patches into registers; U by DMA into the other buffer), then the chunk's MFMAs, then the h = 0 waves transform
-//   the patches (32 add/sub per patch) and write V for g + 1. The chunk stream runs across tiles, so a tile's epilogue and
-//   stores overlap the next tile's loads.
+//   per wave, no registers and no ds_write. One barrier per chunk. Behind the MFMAs of every position of chunk g one slice
+//   of the loads of chunk g + 1 is issued (issued in one block they hold the wave, and half of its SIMD's MFMA supply, for
+//   300-500 cycles per DMA instruction): the input patches first (h = 0 waves; per patch row ONE aligned 8-byte load per
+//   lane, the neighbouring columns from the neighbouring lanes by DPP, a sparse load for the halo column at the ends of the
+//   16-pixel row), then the DMA pieces of U into the other buffer. After the MFMAs the h = 0 waves transform the patches
+//   (32 add/sub per patch) and write V for g + 1. The chunk stream runs across tiles, so a tile's epilogue and stores
+//   overlap the next tile's loads. The result of a tile does not depend on the launch shape.
 // ------------------------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
