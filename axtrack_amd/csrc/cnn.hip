@@ -609,9 +609,14 @@ __device__ __forceinline__ void wino_body(const float *__restrict__ in, const fl
         }
     };
     // DMA piece k of this wave's 5 of U chunk c
+    // every workgroup starts its round through a chunk's 40 pieces elsewhere: the CUs of an XCD run in step, and without
+    // the rotation they all ask the L2 for the same lines at the same moment
+    const int rot = ((blockIdx.x >> 3) * 5) % 40;
     auto dma_piece = [&](int c, int buf, int k) {
-        const float *src = upk + (long)c * G::UBUF + (wave * 5 + k) * 256 + lane * 4;
-        float *dst = Us + buf * G::UBUF + (wave * 5 + k) * 256;
+        int piece = wave * 5 + k + rot;
+        piece = piece >= 40 ? piece - 40 : piece;
+        const float *src = upk + (long)c * G::UBUF + piece * 256 + lane * 4;
+        float *dst = Us + buf * G::UBUF + piece * 256;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                          (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
     };
@@ -686,21 +691,20 @@ __device__ __forceinline__ void wino_body(const float *__restrict__ in, const fl
                     acc[pos][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[slot][s], bq[slot][n][s], acc[pos][n], 0, 0, 0);
             int nvm = 0;
             if constexpr (XFORM) {
-                if (pos < 4) {                      // the patches first: they come from HBM
-                    raw_load(set, pos * 2);
-                    raw_load(set, pos * 2 + 1);
-                    nvm = 4;
-                } else if (pos < 9) {
-                    dma_piece(c_next, buf ^ 1, pos - 4);
+                if (pos < 8) {                          // the patches first: they come from HBM
+                    raw_load(set, pos);
+                    nvm = 2;
+                } else if (pos < 13) {
+                    dma_piece(c_next, buf ^ 1, pos - 8);
                     nvm = 1;
                 }
-            } else if (pos < 5) {
-                dma_piece(c_next, buf ^ 1, pos);
+            } else if (pos >= 6 && pos < 11) {          // (the other waves: after the patch loads have left the address unit)
+                dma_piece(c_next, buf ^ 1, pos - 6);
                 nvm = 1;
             }
             __builtin_amdgcn_sched_group_barrier(0x100, 1 + NTW, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 2 * NTW, 0);
-            if (nvm == 4) __builtin_amdgcn_sched_group_barrier(0x010, 4, 0);
+            if (nvm == 2) __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
             else if (nvm == 1) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
         }
     };
