@@ -24,6 +24,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -658,17 +659,12 @@ __device__ __forceinline__ void wino_body(const float *__restrict__ in, const fl
     };
 
     f32x4 acc[16][NTW];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int pos = 0; pos < 16; ++pos)
-#pragma unroll
-            for (int n = 0; n < NTW; ++n) acc[pos][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    };
     // The MFMAs of the chunk in buffer `buf`. Behind the MFMAs of a position one slice of the loads is issued (in one
     // block at the top of the chunk they would hold the wave, and with it half of the SIMD's MFMA supply, for their whole
     // issue time): the DMA pieces of the next chunk's U into the other buffer, then (transform waves) the raw patches at
     // the load cursor into register set `set`.
-    auto mfma_chunk = [&](int buf, int set, int c_next) {
+    auto mfma_chunk = [&](auto first_tag, int buf, int set, int c_next) {
+        constexpr bool FIRST = decltype(first_tag)::value;          // first chunk of a tile: the accumulators start at zero
         const float *va = Vs + buf * G::VBUF + (m * 64 + lane) * 2;
         const float *ub = Us + buf * G::UBUF + (N0 * 64 + lane) * 2;
         f32x2 a[2], bq[2][NTW];
@@ -688,7 +684,8 @@ __device__ __forceinline__ void wino_body(const float *__restrict__ in, const fl
             for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int n = 0; n < NTW; ++n)
-                    acc[pos][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[slot][s], bq[slot][n][s], acc[pos][n], 0, 0, 0);
+                    acc[pos][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[slot][s], bq[slot][n][s],
+                                                                       (FIRST && s == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[pos][n], 0, 0, 0);
             int nvm = 0;
             if constexpr (XFORM) {
                 if (pos < 8) {                          // the patches first: they come from HBM
@@ -717,30 +714,26 @@ __device__ __forceinline__ void wino_body(const float *__restrict__ in, const fl
         for (int n = 0; n < NTW; ++n) {
             const int ch = (N0 + n) * 16 + p;
             float *och = out + ((long)b * 80 + ch) * Hout * Hout;
-            float y[2][2][4];
+            // 4-vectors over the lane's four tiles (the accumulator registers of one position): packed adds on aligned pairs
+            f32x4 t[2][4], y[2][2];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float t[2][4];
+            for (int jj = 0; jj < 4; ++jj) {
+                t[0][jj] = acc[jj][n] + acc[4 + jj][n] + acc[8 + jj][n];
+                t[1][jj] = acc[4 + jj][n] - acc[8 + jj][n] - acc[12 + jj][n];
+            }
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    t[0][jj] = acc[jj][n][j] + acc[4 + jj][n][j] + acc[8 + jj][n][j];
-                    t[1][jj] = acc[4 + jj][n][j] - acc[8 + jj][n][j] - acc[12 + jj][n][j];
-                }
-#pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    y[a][0][j] = t[a][0] + t[a][1] + t[a][2];
-                    y[a][1][j] = t[a][1] - t[a][2] - t[a][3];
-                }
+            for (int a = 0; a < 2; ++a) {
+                y[a][0] = t[a][0] + t[a][1] + t[a][2];
+                y[a][1] = t[a][1] - t[a][2] - t[a][3];
             }
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int bb = 0; bb < 2; ++bb)
+                for (int bb = 0; bb < 2; ++bb) {
+                    const f32x4 tb = y[a][bb] + bias_v[n];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float t = y[a][bb][j] + bias_v[n];
-                        y[a][bb][j] = POOL ? (t > 0.f ? t : t * 0.1f) : fmaxf(t, t * 0.1f);
-                    }
+                    for (int j = 0; j < 4; ++j) y[a][bb][j] = POOL ? (tb[j] > 0.f ? tb[j] : tb[j] * 0.1f) : fmaxf(tb[j], tb[j] * 0.1f);
+                }
             if constexpr (POOL) {
                 f32x4 r;
 #pragma unroll
@@ -769,7 +762,6 @@ __device__ __forceinline__ void wino_body(const float *__restrict__ in, const fl
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (XFORM) xform_store(0, 0);
     __syncthreads();
-    zero_acc();
 
     // ---- the chunk stream (LDS buffer = parity of the chunk count) ----
     int w_cur = wr.begin, c = 0;
@@ -777,7 +769,8 @@ __device__ __forceinline__ void wino_body(const float *__restrict__ in, const fl
     auto step = [&](int PAR) {
         const bool last = c + 1 == NCH;
         const int c_next = last ? 0 : c + 1;                       // U of the chunk after this one (any tile: same weights)
-        mfma_chunk(PAR, 0, c_next);
+        if (c == 0) mfma_chunk(std::true_type{}, PAR, 0, c_next);
+        else mfma_chunk(std::false_type{}, PAR, 0, c_next);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the patches and this wave's DMA pieces have landed
         if constexpr (XFORM) {
             advance_cursor();
@@ -792,7 +785,6 @@ __device__ __forceinline__ void wino_body(const float *__restrict__ in, const fl
         }
         if (last) {
             epilogue(w_cur);
-            zero_acc();
             c = 0;
             w_cur += wr.step;
             done = w_cur >= wr.end;
