@@ -302,7 +302,7 @@ def verify(args, ad, frames_host, sd, per_rank, world):
     yolo = ad._yolo.cpu().numpy()                          # this rank's frames [per_rank, n_tiles, 12, 12, 3]
     F, n_tiles = yolo.shape[:2]
     per_launch = max(128 // n_tiles, 1)
-    sample = sorted({0, per_launch - 1, per_launch % F, (per_launch + 1) % F, F // 3, F // 2, (2 * F) // 3, F - 1})
+    sample = sorted({0, min(per_launch - 1, F - 1), per_launch % F, (per_launch + 1) % F, F // 3, F // 2, (2 * F) // 3, F - 1})
     err = 0.0
     for t in sample:
         ref = orc.cnn_forward(sd, orc.frame_tile_stack(frames_host, t, ad.tile_yx))
