@@ -10,9 +10,9 @@
 //                    traffic through buffer loads / stores (zero padding from the range check). Block 0 reads the
 //                    5-frame temporal stack straight from the timelapse (fuses Timelapse.get_frametiles_stack,
 //                    Timelapse.py:111-125,150-157).
-//   conv3x3_wino     the same stride-1 blocks with 80 output channels as Winograd F(2x2,3x3) on the same f32 MFMA: 16/36 of
-//                    the multiplications, every operation f32 -- the DEFAULT for conv blocks 2,4,5,7,8 (conv3x3_mfma stays
-//                    selectable: axt_detector_set_arith; conv block 10 always runs on it).
+//   conv3x3_wino     the same stride-1 blocks as Winograd F(2x2,3x3) on the same f32 MFMA: 16/36 of the multiplications,
+//                    every operation f32 -- the DEFAULT for conv blocks 2,4,5,7,8,10 (output channels in groups of 80;
+//                    conv3x3_mfma stays selectable: axt_detector_set_arith).
 //   gemm_mfma        split-K GEMM for the three linear layers, partial slabs reduced in a fixed order
 //                    (bit-reproducible) by reduce_bias_act (+ Sigmoid).
 //
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3(
 }
 
 // ------------------------------------------------------------------------------------------------
-// conv3x3_wino: the stride-1 blocks with 80 output channels as Winograd F(2x2, 3x3) on the f32 matrix pipe.
+// conv3x3_wino: the stride-1 blocks (80 output channels, or NG groups of 80) as Winograd F(2x2, 3x3) on the f32 matrix pipe.
 //   Y = A^T [ (G g G^T) . (B^T d B) ] A per 2x2 output tile (Lavin & Gray 2016): 16 multiplies per tile, input and output
 //   channel instead of 36 -- the 16 transform positions are 16 independent GEMMs  M_pos[tile][cout] = V_pos[tile][cin] *
 //   U_pos[cin][cout]  on v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate; all arithmetic stays f32: the transforms are
@@ -545,7 +545,7 @@ struct GeoW {
     static constexpr int LDS_B = 2 * (VBUF + UBUF) * 4;   // 147456
 };
 
-template <int CIN, bool POOL, int NTW, bool XFORM>
+template <int CIN, bool POOL, int NTW, bool XFORM, int NG>
 __device__ __forceinline__ void wino_body(const float *__restrict__ in, const float *__restrict__ upk,
                                           const float *__restrict__ bias, float *__restrict__ out, int H, int B, float *smem)
 {
@@ -556,15 +556,20 @@ __device__ __forceinline__ void wino_body(const float *__restrict__ in, const fl
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 15, q = lane >> 4;
     const int m = wave & 3;
     const int tiles_x = H >> 4, ntile = tiles_x * tiles_x;
-    const WorkRange wr = my_work(ntile * B);
+    // work item w = ((batch item * NG) + group of 80 output channels) * ntile + tile
+    const WorkRange wr = my_work(ntile * B * NG);
     if (wr.begin >= wr.end) return;
     const int cstride = H * H;
     const int Hout = POOL ? H / 2 : H;
     float *Vs = smem, *Us = smem + 2 * G::VBUF;
+    auto group_of = [&](int w) { return NG == 1 ? 0 : (w / ntile) % NG; };
 
     float bias_v[NTW];
+    auto load_bias = [&](int grp) {
 #pragma unroll
-    for (int n = 0; n < NTW; ++n) bias_v[n] = bias[(N0 + n) * 16 + p];
+        for (int n = 0; n < NTW; ++n) bias_v[n] = bias[grp * 80 + (N0 + n) * 16 + p];
+    };
+    load_bias(group_of(wr.begin));
 
     // ---- raw patches (transform waves): fetched one chunk ahead of their use ----
     // A patch row = [left][mid.x mid.y][right] at columns x0 + 2 tx - 1 .. + 2. Every lane loads only its aligned middle
@@ -577,7 +582,7 @@ __device__ __forceinline__ void wino_body(const float *__restrict__ in, const fl
     const bool first_col = (p & 7) == 0, last_col = (p & 7) == 7;
     int lw = wr.begin, lc = 0;                      // load cursor: tile and chunk of the next patches to fetch
     auto plan_tile = [&](int w) {
-        const int tile = w % ntile, b = w / ntile;
+        const int tile = w % ntile, b = w / (ntile * NG);
         ld_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in) + (long)b * CIN * cstride, 0, kBufRecords, 0x00020000);
         const int y0 = (tile / tiles_x) * 16, x0 = (tile % tiles_x) * 16;
         const int ty = 2 * m + (p >> 3), tx = p & 7;
@@ -613,7 +618,7 @@ __device__ __forceinline__ void wino_body(const float *__restrict__ in, const fl
     // every workgroup starts its round through a chunk's 40 pieces elsewhere: the CUs of an XCD run in step, and without
     // the rotation they all ask the L2 for the same lines at the same moment
     const int rot = ((blockIdx.x >> 3) * 5) % 40;
-    auto dma_piece = [&](int c, int buf, int k) {
+    auto dma_piece = [&](int c, int buf, int k) {               // c: chunk index in the packed image (group * NCH + chunk)
         int piece = wave * 5 + k + rot;
         piece = piece >= 40 ? piece - 40 : piece;
         const float *src = upk + (long)c * G::UBUF + piece * 256 + lane * 4;
@@ -707,13 +712,13 @@ __device__ __forceinline__ void wino_body(const float *__restrict__ in, const fl
     };
     // A^T M A, bias, LeakyReLU(0.1) (+ 2x2 max) and the stores of tile w
     auto epilogue = [&](int w) {
-        const int tile = w % ntile, b = w / ntile;
+        const int tile = w % ntile, b = w / (ntile * NG), grp = group_of(w);
         const int y0 = (tile / tiles_x) * 16, x0 = (tile % tiles_x) * 16;
         const int ty = 2 * m + (q >> 1), txb = 4 * (q & 1);          // this lane's tiles: row ty, columns txb .. txb + 3
 #pragma unroll
         for (int n = 0; n < NTW; ++n) {
             const int ch = (N0 + n) * 16 + p;
-            float *och = out + ((long)b * 80 + ch) * Hout * Hout;
+            float *och = out + ((long)b * (80 * NG) + grp * 80 + ch) * Hout * Hout;
             // 4-vectors over the lane's four tiles (the accumulator registers of one position): packed adds on aligned pairs
             f32x4 t[2][4], y[2][2];
 #pragma unroll
@@ -758,7 +763,7 @@ __device__ __forceinline__ void wino_body(const float *__restrict__ in, const fl
         advance_cursor();
     }
 #pragma unroll
-    for (int k = 0; k < 5; ++k) dma_piece(0, 0, k);
+    for (int k = 0; k < 5; ++k) dma_piece(group_of(wr.begin) * NCH, 0, k);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (XFORM) xform_store(0, 0);
     __syncthreads();
@@ -768,7 +773,9 @@ __device__ __forceinline__ void wino_body(const float *__restrict__ in, const fl
     bool done = false;
     auto step = [&](int PAR) {
         const bool last = c + 1 == NCH;
-        const int c_next = last ? 0 : c + 1;                       // U of the chunk after this one (any tile: same weights)
+        // U of the chunk after this one: the next chunk of this tile's group, or the first chunk of the next tile's group
+        const int w_after = w_cur + wr.step < wr.end ? w_cur + wr.step : w_cur;
+        const int c_next = last ? group_of(w_after) * NCH : group_of(w_cur) * NCH + c + 1;
         if (c == 0) mfma_chunk(std::true_type{}, PAR, 0, c_next);
         else mfma_chunk(std::false_type{}, PAR, 0, c_next);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the patches and this wave's DMA pieces have landed
@@ -788,6 +795,7 @@ __device__ __forceinline__ void wino_body(const float *__restrict__ in, const fl
             c = 0;
             w_cur += wr.step;
             done = w_cur >= wr.end;
+            if (NG > 1 && !done) load_bias(group_of(w_cur));
         } else ++c;
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
@@ -796,16 +804,16 @@ __device__ __forceinline__ void wino_body(const float *__restrict__ in, const fl
     while (!done);
 }
 
-template <int CIN, bool POOL>
+template <int CIN, bool POOL, int NG>
 __global__ __launch_bounds__(512, 1) void conv3x3_wino(const float *__restrict__ in,      // activations [B,CIN,H,H]
                                                        const float *__restrict__ upk,     // pack_wino image
-                                                       const float *__restrict__ bias,    // folded bias [80]
-                                                       float *__restrict__ out,           // [B,80,Hout,Hout]
+                                                       const float *__restrict__ bias,    // folded bias [80*NG]
+                                                       float *__restrict__ out,           // [B,80*NG,Hout,Hout]
                                                        int H, int B)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    if ((threadIdx.x >> 8) == 0) wino_body<CIN, POOL, 2, true>(in, upk, bias, out, H, B, smem);
-    else wino_body<CIN, POOL, 3, false>(in, upk, bias, out, H, B, smem);
+    if ((threadIdx.x >> 8) == 0) wino_body<CIN, POOL, 2, true, NG>(in, upk, bias, out, H, B, smem);
+    else wino_body<CIN, POOL, 3, false, NG>(in, upk, bias, out, H, B, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1313,7 +1321,7 @@ struct axt_detector {
     unsigned *d_wb3[8] = {};    // conv blocks 2..6 packed for conv3x3_bf16x3 (allocated on the first switch to that arithmetic)
     std::vector<float> h_wfold[8];   // their BN-folded f32 weights [cout][cin][3][3], kept on the host for that packing
     float *d_wwino[8] = {};     // conv blocks 2..6 packed for conv3x3_wino (allocated on the first switch to that arithmetic)
-    int arith = 0;              // stride-1 blocks with 80 output channels: 0 direct f32 MFMA | 1 bf16x3 | 2 f32 Winograd F(2x2,3x3) (set by create)
+    int arith = 0;              // stride-1 blocks: 0 direct f32 MFMA | 1 bf16x3 (blocks 2..8) | 2 f32 Winograd F(2x2,3x3) (set by create)
     float *d_bconv[8] = {};     // folded bias
     float *d_wfc[3] = {};       // [K][Npad]
     float *d_bfc[3] = {};
@@ -1486,20 +1494,20 @@ int persistent_grid(int nwork, int per_cu)
 }
 
 // Packs the BN-folded weights [80][cin][3][3] of a stride-1 block for conv3x3_wino: U = G g G^T (f64, rounded once) in
-// the LDS image order [chunk of 8 channels][pos 16][channel block 5][lane = q*16 + p][k-step 2]:
-// input channel chunk*8 + s*4 + q, output channel block*16 + p.
-void pack_wino(int cin, const std::vector<float> &wfold, std::vector<float> &out)
+// the LDS image order [group of 80 output channels][chunk of 8 channels][pos 16][channel block 5][lane = q*16 + p][k-step 2]:
+// input channel chunk*8 + s*4 + q, output channel group*80 + block*16 + p.
+void pack_wino(int cin, int cout, const std::vector<float> &wfold, std::vector<float> &out)
 {
     static const double Gm[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
     const int nchunk = cin / GeoW::CCH;
-    out.assign((size_t)nchunk * GeoW::UBUF, 0.f);
-    for (int co = 0; co < 80; ++co)
+    out.assign((size_t)(cout / 80) * nchunk * GeoW::UBUF, 0.f);
+    for (int co = 0; co < cout; ++co)
         for (int ci = 0; ci < cin; ++ci) {
             const float *g = &wfold[((size_t)co * cin + ci) * 9];
             double tmp[4][3];
             for (int i = 0; i < 4; ++i)
                 for (int b = 0; b < 3; ++b) tmp[i][b] = Gm[i][0] * g[0 * 3 + b] + Gm[i][1] * g[1 * 3 + b] + Gm[i][2] * g[2 * 3 + b];
-            const int chunk = ci / 8, s = (ci % 8) / 4, q = ci % 4, n = co / 16, p = co % 16;
+            const int chunk = (co / 80) * nchunk + ci / 8, s = (ci % 8) / 4, q = ci % 4, n = (co % 80) / 16, p = co % 16;
             for (int i = 0; i < 4; ++i)
                 for (int j = 0; j < 4; ++j) {
                     const double u = tmp[i][0] * Gm[j][0] + tmp[i][1] * Gm[j][1] + tmp[i][2] * Gm[j][2];
@@ -1508,10 +1516,10 @@ void pack_wino(int cin, const std::vector<float> &wfold, std::vector<float> &out
         }
 }
 
-template <int CIN, bool POOL>
+template <int CIN, bool POOL, int NG = 1>
 int launch_conv_wino(const float *in, const float *u, const float *bias, float *out, int Hin, int B, hipStream_t st)
 {
-    auto kern = conv3x3_wino<CIN, POOL>;
+    auto kern = conv3x3_wino<CIN, POOL, NG>;
     static bool attr_set = false;
     if (!attr_set) {
         AXT_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GeoW::LDS_B));
@@ -1519,7 +1527,7 @@ int launch_conv_wino(const float *in, const float *u, const float *bias, float *
     }
     AXT_REQUIRE(Hin % 16 == 0 && u != nullptr, "conv (winograd): map size %d not a multiple of the 16x16 tile, or weights not packed", Hin);
     AXT_REQUIRE((double)CIN * Hin * Hin * 4 < 2.0e9, "conv (winograd): map too large");
-    const int nwork = (Hin / 16) * (Hin / 16) * B;
+    const int nwork = (Hin / 16) * (Hin / 16) * B * NG;
     hipLaunchKernelGGL(kern, dim3(persistent_grid(nwork, 1)), dim3(512), GeoW::LDS_B, st, in, u, bias, out, Hin, B);
     AXT_LAUNCH_CHECK();
     return AXT_OK;
@@ -1694,8 +1702,9 @@ int run_back(axt_detector *d, int nb, float *d_yolo, hipStream_t st)
     }
     {
         ProfSpan ps(d, st, 7, nb);
-        if ((rc = launch_conv<80, 160, false, 8, 5>(d->d_act[6], d->d_wconv[7], d->d_bconv[7], d->d_act[7],
-                                                                 16, 2, nb, st))) return rc;
+        rc = d->arith == 2 ? launch_conv_wino<80, false, 2>(d->d_act[6], d->d_wwino[7], d->d_bconv[7], d->d_act[7], 16, nb, st)
+                           : launch_conv<80, 160, false, 8, 5>(d->d_act[6], d->d_wconv[7], d->d_bconv[7], d->d_act[7], 16, 2, nb, st);
+        if (rc) return rc;
     }
     {
         ProfSpan ps(d, st, 8, nb);
@@ -1773,7 +1782,7 @@ int axt_detector_create(const float *const *h_tensors, int n_tensors, int max_ba
     std::vector<float> wp, bp;
     for (int li = 0; li < 8 && !rc; ++li) {
         const float *const *t = h_tensors + li * 6;
-        pack_conv(li, t[0], t[1], t[2], t[3], t[4], t[5], wp, bp, (li >= 2 && li <= 6) ? &d->h_wfold[li] : nullptr);
+        pack_conv(li, t[0], t[1], t[2], t[3], t[4], t[5], wp, bp, (li >= 2 && li <= 7) ? &d->h_wfold[li] : nullptr);
         if ((rc = dev_alloc(d, &d->d_wconv[li], wp.size()))) break;
         if ((rc = dev_alloc(d, &d->d_bconv[li], bp.size()))) break;
         if (hipMemcpy(d->d_wconv[li], wp.data(), wp.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
@@ -1832,8 +1841,8 @@ int axt_detector_set_arith(axt_detector *d, int mode)
     }
     if (mode == 2 && !d->d_wwino[2]) {
         std::vector<float> pk;
-        for (int li = 2; li <= 6; ++li) {
-            pack_wino(kConv[li].cin, d->h_wfold[li], pk);
+        for (int li = 2; li <= 7; ++li) {
+            pack_wino(kConv[li].cin, kConv[li].cout, d->h_wfold[li], pk);
             const int rc = dev_alloc(d, &d->d_wwino[li], pk.size());
             if (rc) return rc;
             AXT_CHECK_HIP(hipMemcpy(d->d_wwino[li], pk.data(), pk.size() * 4, hipMemcpyHostToDevice));

@@ -69,7 +69,7 @@ class Detector:
         self.set_arith(arith)
 
     def set_arith(self, arith):
-        """Arithmetic of the stride-1 conv blocks with 80 output channels (parameters['CNN_ARITH']): 'f32' (default; the
+        """Arithmetic of the stride-1 conv blocks (parameters['CNN_ARITH']): 'f32' (default; the
         same as 'f32_winograd': Winograd F(2x2,3x3) on the f32 matrix pipe, every operation f32), 'f32_direct' (direct
         convolution on the f32 matrix pipe: a k-ordered chain of f32 FMAs) or 'bf16x3' (opt-in: operands split into three
         bf16 terms, six partial products on the bf16 matrix pipe, f32 accumulation). See axt_detector_set_arith."""

@@ -96,7 +96,7 @@ def main():
     P['ASSOCIATION'] = args.assoc
     P['CNN_ARITH'] = args.arith
     winograd = args.arith in ('f32', 'f32_winograd')
-    wino_blocks = ('conv2', 'conv4', 'conv5', 'conv7', 'conv8')          # the stride-1 blocks with 80 output channels
+    wino_blocks = ('conv2', 'conv4', 'conv5', 'conv7', 'conv8', 'conv10')  # the stride-1 blocks (Winograd in the default arithmetic)
     n_tiles = (-(-H // 512)) * (-(-W // 512))
     model = axtrack_amd.Detector(sd, max_batch=min(per_rank * n_tiles, 1024), device=dev)
     tl = axtrack_amd.Timelapse(frames, name='bench', device=dev)
@@ -232,7 +232,7 @@ def main():
                        'detection_frames_per_gpu': per_rank, 'tiles_per_frame': n_tiles,
                        'weights': 'random-init (synth seed 42)', 'parallelism': f'frame-sharded x{world}',
                        'cnn_arith': args.arith,
-                       'conv_algorithm': ('Winograd F(2x2,3x3), f32, for conv blocks 2,4,5,7,8 (stride 1, 80 output channels); direct elsewhere'
+                       'conv_algorithm': ('Winograd F(2x2,3x3), f32, for the six stride-1 conv blocks (2,4,5,7,8,10); direct for the two stride-2 blocks'
                                           if winograd else 'direct')},
             'stages': stages,
             'detections': int(ad._host_dets()[0].sum()),

@@ -62,8 +62,8 @@ int axt_detector_create(const float *const *h_tensors, int n_tensors, int max_ba
                         axt_detector **out);
 void axt_detector_destroy(axt_detector *det);
 
-/* Arithmetic of the stride-1 conv blocks with 80 output channels (blocks 2, 4, 5, 7, 8 of model.py:85-103; 71 % of the
- * forward pass's FLOPs); parameters['CNN_ARITH'].
+/* Arithmetic of the stride-1 conv blocks (blocks 2, 4, 5, 7, 8, 10 of model.py:85-103; 73 % of the forward pass's FLOPs;
+ * mode 1 leaves block 10 on the direct kernel); parameters['CNN_ARITH'].
  * mode 2 (default after axt_detector_create, "f32" / "f32_winograd"): Winograd F(2x2,3x3) on the f32 matrix pipe -- every
  *   operation f32 (transforms are additions, G g G^T formed in f64 and rounded once), 16/36 of the direct multiplications;
  *   as close to an f64 convolution as the direct kernel, like the algorithms cuDNN / oneDNN choose for

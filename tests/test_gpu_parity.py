@@ -1376,7 +1376,7 @@ def test_cnn_bf16x3_arithmetic_against_oracle_and_f32_path(golden, weights):
 
 
 def test_cnn_winograd_and_direct_arithmetic_against_oracle(golden, weights):
-    """parameters['CNN_ARITH']: 'f32' (the default, = 'f32_winograd': the stride-1 conv blocks with 80 output channels as
+    """parameters['CNN_ARITH']: 'f32' (the default, = 'f32_winograd': the six stride-1 conv blocks as
     Winograd F(2x2,3x3) on the f32 matrix pipe, all arithmetic f32) and 'f32_direct' (direct convolution on the f32 matrix
     pipe). Both within the same tolerance of the reference's golden grids and of the oracle's f32 forward pass (zero padding
     of every layer, hot corner pixels, ragged frames whose width is not a multiple of 4, a batch that leaves the persistent
