@@ -617,7 +617,7 @@ __device__ __forceinline__ void wino_body(const float *__restrict__ in, const fl
     // DMA piece k of this wave's 5 of U chunk c
     // every workgroup starts its round through a chunk's 40 pieces elsewhere: the CUs of an XCD run in step, and without
     // the rotation they all ask the L2 for the same lines at the same moment
-    const int rot = ((blockIdx.x >> 3) * 5) % 40;
+    const int rot = (blockIdx.x * 7) % 40;
     auto dma_piece = [&](int c, int buf, int k) {               // c: chunk index in the packed image (group * NCH + chunk)
         int piece = wave * 5 + k + rot;
         piece = piece >= 40 ? piece - 40 : piece;
