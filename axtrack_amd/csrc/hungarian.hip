@@ -82,7 +82,7 @@ __global__ __launch_bounds__(64) void hungarian_pair_kernel(
     int dmax, const long *__restrict__ units, long thr_units,
     const int *__restrict__ succ1, const int *__restrict__ pred1,
     int *__restrict__ succ_out, int *__restrict__ pred_out, int cdim, int t_first,
-    const short *__restrict__ dtab, int tab_gaps)
+    const short *__restrict__ dtab, int tab_gaps, const long *__restrict__ ctab)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
     const int t = t_first + blockIdx.x, tb = t + GAP, lane = threadIdx.x;
@@ -123,6 +123,8 @@ __global__ __launch_bounds__(64) void hungarian_pair_kernel(
     // cost of linking row i to column j (HINF: not admitted)
     auto link_cost = [&](int i, int j) -> long {
         if (!col_ok[j]) return HINF;
+        if (ctab)                            // link costs given per pair (the appearance term: axt_hungarian_pairs_costs)
+            return ctab[(((long)t * cap + i) * tab_gaps + (GAP - 1)) * cap + j];
         int d;
         if (dtab) {                          // masked grid: path lengths from the arc builder's searches (<= 0: none)
             d = dtab[(((long)t * cap + i) * tab_gaps + (GAP - 1)) * cap + j];
@@ -461,10 +463,10 @@ __global__ void range_count_kernel(const int *__restrict__ count, int *__restric
 }
 }  // namespace
 
-extern "C" int axt_hungarian_pairs_grid(const int32_t *d_x, const int32_t *d_y, const int32_t *d_count, int n_frames, int cap,
-                                        const axt_grid *grid, int H, int W, int max_dist, int conn8, int max_gap,
-                                        const int32_t *h_dmax, const int64_t *d_cost_units, int64_t thr_units, int t_begin,
-                                        int t_end, int32_t *d_pred, int32_t *d_work, void *stream)
+static int hungarian_pairs_impl(const int32_t *d_x, const int32_t *d_y, const int32_t *d_count, int n_frames, int cap,
+                                const axt_grid *grid, int H, int W, int max_dist, int conn8, int max_gap,
+                                const int32_t *h_dmax, const int64_t *d_cost_units, int64_t thr_units, int t_begin,
+                                int t_end, int32_t *d_pred, int32_t *d_work, void *stream, const int64_t *d_ctab)
 {
     AXT_REQUIRE(d_x && d_y && d_count && h_dmax && d_cost_units && d_work && d_pred, "null argument");
     AXT_REQUIRE(n_frames >= 1 && cap >= 1 && cap <= 2048, "axt_hungarian_pairs: cap %d out of range [1,2048]", cap);
@@ -502,7 +504,7 @@ extern "C" int axt_hungarian_pairs_grid(const int32_t *d_x, const int32_t *d_y, 
     // arc builder (path_bfs.hip), read by the pair kernels instead of the closed form
     short *dtab = nullptr;
     int *aux = nullptr;
-    if (grid && e1 > t_begin) {
+    if (grid && !d_ctab && e1 > t_begin) {
         AXT_CHECK_HIP(hipMallocAsync((void **)&dtab, sizeof(short) * (size_t)n_frames * cap * max_gap * cap, st));
         AXT_CHECK_HIP(hipMallocAsync((void **)&aux, sizeof(int) * ((size_t)n_frames + max_gap), st));
         int *src_count = aux, *dmax_dev = aux + n_frames;
@@ -515,7 +517,8 @@ extern "C" int axt_hungarian_pairs_grid(const int32_t *d_x, const int32_t *d_y, 
     if (e1 > t_begin) {
         hipLaunchKernelGGL((cap <= 192 ? hungarian_pair_kernel<1, 3> : cap <= 576 ? hungarian_pair_kernel<1, 9> : hungarian_pair_kernel<1, 0>), dim3(e1 - t_begin), dim3(64), lds, st, d_x, d_y, d_count, frame_off,
                            n_frames, cap, H, W, max_dist, conn8, h_dmax[0], (const long *)d_cost_units, (long)thr_units,
-                           (const int *)nullptr, (const int *)nullptr, succ1, pred1, cdim, t_begin, (const short *)dtab, max_gap);
+                           (const int *)nullptr, (const int *)nullptr, succ1, pred1, cdim, t_begin, (const short *)dtab, max_gap,
+                           (const long *)d_ctab);
         AXT_LAUNCH_CHECK();
     }
     const int e2 = t_end < n_frames - 2 ? t_end : n_frames - 2;
@@ -523,7 +526,7 @@ extern "C" int axt_hungarian_pairs_grid(const int32_t *d_x, const int32_t *d_y, 
         hipLaunchKernelGGL((cap <= 192 ? hungarian_pair_kernel<2, 3> : cap <= 576 ? hungarian_pair_kernel<2, 9> : hungarian_pair_kernel<2, 0>), dim3(e2 - t_begin), dim3(64), lds, st, d_x, d_y, d_count, frame_off,
                            n_frames, cap, H, W, max_dist, conn8, h_dmax[1],
                            (const long *)d_cost_units + (max_dist + 1), (long)thr_units, (const int *)succ1,
-                           (const int *)pred1, succ2, pred2, cdim, t_begin, (const short *)dtab, max_gap);
+                           (const int *)pred1, succ2, pred2, cdim, t_begin, (const short *)dtab, max_gap, (const long *)d_ctab);
         AXT_LAUNCH_CHECK();
     }
     if (dtab) {
@@ -531,6 +534,29 @@ extern "C" int axt_hungarian_pairs_grid(const int32_t *d_x, const int32_t *d_y, 
         AXT_CHECK_HIP(hipFreeAsync(aux, st));
     }
     return AXT_OK;
+}
+
+extern "C" int axt_hungarian_pairs_grid(const int32_t *d_x, const int32_t *d_y, const int32_t *d_count, int n_frames, int cap,
+                                        const axt_grid *grid, int H, int W, int max_dist, int conn8, int max_gap,
+                                        const int32_t *h_dmax, const int64_t *d_cost_units, int64_t thr_units, int t_begin,
+                                        int t_end, int32_t *d_pred, int32_t *d_work, void *stream)
+{
+    return hungarian_pairs_impl(d_x, d_y, d_count, n_frames, cap, grid, H, W, max_dist, conn8, max_gap, h_dmax, d_cost_units,
+                                thr_units, t_begin, t_end, d_pred, d_work, stream, nullptr);
+}
+
+// The same passes with the link costs GIVEN: d_ctab i64 [n_frames][cap][max_gap][cap], entry (t, i, g-1, j) = the integer cost
+// (axt_arc_cost_int, kind 3, global detection indices) of linking detection i of frame t to detection j of frame t+g, or
+// 0x3fffffffffffffff where the link is not admitted. Used for cost models the closed form does not cover (the appearance
+// term: the costs of axt_build_arcs_vis scattered into the table).
+extern "C" int axt_hungarian_pairs_costs(const int32_t *d_x, const int32_t *d_y, const int32_t *d_count, int n_frames, int cap,
+                                         int max_gap, const int64_t *d_ctab, int64_t thr_units, int t_begin, int t_end,
+                                         int32_t *d_pred, int32_t *d_work, void *stream)
+{
+    AXT_REQUIRE(d_ctab != nullptr, "axt_hungarian_pairs_costs: null cost table");
+    const int32_t dmax0[2] = {0, 0};
+    return hungarian_pairs_impl(d_x, d_y, d_count, n_frames, cap, nullptr, 1 << 20, 1 << 20, 1, 0, max_gap, dmax0,
+                                (const int64_t *)d_ctab, thr_units, t_begin, t_end, d_pred, d_work, stream, d_ctab);
 }
 
 extern "C" int axt_hungarian_pairs(const int32_t *d_x, const int32_t *d_y, const int32_t *d_count, int n_frames, int cap,

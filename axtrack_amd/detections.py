@@ -594,20 +594,31 @@ class AxonDetections(object):
         vis_w = P['MCF_VIS_SIM_WEIGHT']
         dmax, units = _cost_units_on_device(P, self.max_px_assoc_dist, self.device)
         mode = P.get('ASSOCIATION', 'mcf')
-        if vis_w and mode != 'mcf':
-            raise NotImplementedError("MCF_VIS_SIM_WEIGHT > 0 is implemented for ASSOCIATION='mcf' only")
         masked = self.dataset.masked
         varying = self.dataset.mask3d is not None
         shard = getattr(self, '_shard', None)           # set by gather_detections(): solve only this rank's frame pairs
         if mode == 'hungarian':
             if varying:
                 raise NotImplementedError("a time-varying mask is implemented for ASSOCIATION='mcf' (the reference's tracker) only")
+            ctab = None
+            if vis_w:
+                # the appearance term: the link costs are those of the flow tracker's arcs (axt_build_arcs_vis: the same
+                # admission, the same integers), scattered into a dense table per frame pair
+                hist, hsum = self._appearance()
+                vis = dict(hist=hist, hsum=hsum, weight=vis_w, miss_rate=P['MCF_MISS_RATE'], thr=P['MCF_EDGE_COST_THR'])
+                len_table = None
+                if masked and max(dmax) - 1 > 250:       # beyond the hot-path search window: the exact lengths (as for 'mcf')
+                    len_table = self._length_table_from_dists(self.astar_dists())
+                row_ptr, col, _, gap, cost = hp.build_arcs(self.d_x, self.d_y, self.d_count, self.dataset.sizey,
+                                                           self.dataset.sizex, dmax, units, self._mask_dev(),
+                                                           self.max_px_assoc_dist, self.conn8, vis, len_table, None)
+                ctab = self._hungarian_cost_table(row_ptr, col, gap, cost, len(dmax))
             track, n_tracks = hp.hungarian_assoc(self.d_x, self.d_y, self.d_count, self.dataset.sizey,
                                                  self.dataset.sizex, dmax, units,
                                                  int(np.rint(P['MCF_EDGE_COST_THR'] * 1e6)),
                                                  self.max_px_assoc_dist, self.conn8,
                                                  *(((shard[0], shard[1]), shard[2]) if shard else (None, None)),
-                                                 mask=self._mask_dev() if masked else None)
+                                                 mask=self._mask_dev() if masked else None, ctab=ctab)
             self._d_track, self._track_flat_cache = track, None       # host copies are made on first use only
             self.n_ids, self.mcf_total_cost = int(n_tracks.item()), None
             return True
@@ -664,6 +675,26 @@ class AxonDetections(object):
         self.mcf_total_cost, self.n_ids = total, n_tracks
         self._track_flat_cache, self._d_track = track, None
         return True
+
+    def _hungarian_cost_table(self, row_ptr, col, gap, cost, gaps):
+        """Arcs (CSR by global tail index, global head indices, integer costs) -> i64 [F, cap, gaps, cap] with
+        hp.HUNGARIAN_NO_LINK where there is no arc: what axt_hungarian_pairs_costs reads. All on the device."""
+        F, cap = self.d_x.shape
+        if F * cap * gaps * cap * 8 > 4 << 30:
+            raise NotImplementedError(f'the cost table of {F} frames x {cap} detection slots would take '
+                                      f'{F * cap * gaps * cap * 8 / 2 ** 30:.1f} GiB')
+        dev = self.device
+        offs = torch.zeros((F + 1,), dtype=torch.int64, device=dev)
+        offs[1:] = torch.cumsum(self.d_count.long(), 0)
+        n_det = int(offs[-1].item())
+        deg = (row_ptr[1:n_det + 1] - row_ptr[:n_det]).long()
+        tail = torch.repeat_interleave(torch.arange(n_det, device=dev), deg, output_size=len(col))
+        ft = torch.searchsorted(offs, tail, right=True) - 1
+        head = col.long()
+        fb = torch.searchsorted(offs, head, right=True) - 1
+        tab = torch.full((F, cap, gaps, cap), hp.HUNGARIAN_NO_LINK, dtype=torch.int64, device=dev)
+        tab[ft, tail - offs[ft], gap.long() - 1, head - offs[fb]] = cost
+        return tab
 
     @property
     def _offs(self):

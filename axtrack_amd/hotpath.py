@@ -359,12 +359,17 @@ def build_arcs(x, y, count, H, W, dmax, cost_units=None, mask=None, max_dist=MAX
     return row_ptr, col[:n], length[:n], gap[:n], (cost[:n] if cost is not None else None)
 
 
+HUNGARIAN_NO_LINK = 0x3fffffffffffffff          # entry of a cost table where a link is not admitted
+
+
 def hungarian_assoc(x, y, count, H, W, dmax, cost_units, thr_units, max_dist=MAX_PX_ASSOC_DIST, conn8=False,
-                    frame_range=None, group=None, mask=None):
+                    frame_range=None, group=None, mask=None, ctab=None):
     """Frame-to-frame Hungarian association (BASELINE config 3) of a whole timelapse on the GPU.
     frame_range=(a, b): this rank solves only the pairs of source frames a..b-1; the link arrays are then
     combined over `group` with one MAX all-reduce and every rank numbers the chains (frame-sharded runs).
     mask: None (all-ones) or a Grid: path lengths then come from the masked-grid searches of the arc builder.
+    ctab: optional i64 device tensor [F, cap, len(dmax), cap] of link costs (HUNGARIAN_NO_LINK where not admitted), used
+    instead of the costs derived from the path lengths (axt_hungarian_pairs_costs; the appearance term).
     Returns (track i32 [F,cap] device tensor, n_tracks device tensor [1])."""
     n_frames, cap = x.shape
     max_gap = len(dmax)
@@ -379,11 +384,18 @@ def hungarian_assoc(x, y, count, H, W, dmax, cost_units, thr_units, max_dist=MAX
     a, b = (0, n_frames) if frame_range is None else frame_range
     lib = _lib.load()
     with torch.cuda.device(dev):
-        _lib.check(lib.axt_hungarian_pairs_grid(x.data_ptr(), y.data_ptr(), count.data_ptr(), n_frames, cap,
-                                                mask._h if mask is not None else None, H, W,
-                                                int(max_dist), int(bool(conn8)), max_gap, h_dmax.ctypes.data,
-                                                cu.data_ptr(), int(thr_units), int(a), int(b), pred.data_ptr(),
-                                                work.data_ptr(), _stream()), 'axt_hungarian_pairs_grid')
+        if ctab is not None:
+            if ctab.dtype != torch.int64 or tuple(ctab.shape) != (n_frames, cap, max_gap, cap) or not ctab.is_contiguous():
+                raise ValueError(f'ctab must be a contiguous int64 tensor [{n_frames}, {cap}, {max_gap}, {cap}]')
+            _lib.check(lib.axt_hungarian_pairs_costs(x.data_ptr(), y.data_ptr(), count.data_ptr(), n_frames, cap, max_gap,
+                                                     ctab.data_ptr(), int(thr_units), int(a), int(b), pred.data_ptr(),
+                                                     work.data_ptr(), _stream()), 'axt_hungarian_pairs_costs')
+        else:
+            _lib.check(lib.axt_hungarian_pairs_grid(x.data_ptr(), y.data_ptr(), count.data_ptr(), n_frames, cap,
+                                                    mask._h if mask is not None else None, H, W,
+                                                    int(max_dist), int(bool(conn8)), max_gap, h_dmax.ctypes.data,
+                                                    cu.data_ptr(), int(thr_units), int(a), int(b), pred.data_ptr(),
+                                                    work.data_ptr(), _stream()), 'axt_hungarian_pairs_grid')
         if frame_range is not None:
             import torch.distributed as dist
             from . import sharded

@@ -318,6 +318,15 @@ int axt_hungarian_pairs_grid(const int32_t *d_x, const int32_t *d_y, const int32
                              const axt_grid *grid, int H, int W, int max_dist, int conn8, int max_gap,
                              const int32_t *h_dmax, const int64_t *d_cost_units, int64_t thr_units,
                              int t_begin, int t_end, int32_t *d_pred, int32_t *d_work, void *stream);
+/* The same two passes with the link costs GIVEN instead of derived from the path lengths: d_ctab i64
+ * [n_frames][cap][max_gap][cap], entry (t, i, g-1, j) = the integer cost (axt_arc_cost_int, kind 3, global detection
+ * indices) of linking detection i of frame t to detection j of frame t+g, or 0x3fffffffffffffff where the link is not
+ * admitted. For cost models the closed form does not cover -- the appearance term of transition_model
+ * (mincostflow_models.py:107-113, MCF_VIS_SIM_WEIGHT > 0): the costs of axt_build_arcs_vis scattered into the table.
+ * Build-side variant like axt_hungarian_pairs itself (the reference runs only the flow tracker). */
+int axt_hungarian_pairs_costs(const int32_t *d_x, const int32_t *d_y, const int32_t *d_count, int n_frames, int cap,
+                              int max_gap, const int64_t *d_ctab, int64_t thr_units, int t_begin, int t_end,
+                              int32_t *d_pred, int32_t *d_work, void *stream);
 int axt_chain_tracks(const int32_t *d_count, int n_frames, int cap, const int32_t *d_pred, int32_t *d_work,
                      int32_t *d_track, int32_t *d_n_tracks, void *stream);
 

@@ -427,7 +427,7 @@ def mcf_solve(dets, D, P=DEFAULTS, name='synth', images=None):
 
 
 # ------------------------------------------------------------------------------- config 3 variant
-def hungarian_assoc(dets, H, W, P=DEFAULTS, mask=None):
+def hungarian_assoc(dets, H, W, P=DEFAULTS, mask=None, images=None):
     """Frame-to-frame Hungarian association (BASELINE config 3; the reference has no such code,
     SURVEY.md F7 -- this is the build's own definition, solved here with SciPy's
     linear_sum_assignment as the independent exact solver).
@@ -437,12 +437,16 @@ def hungarian_assoc(dets, H, W, P=DEFAULTS, mask=None):
     transition_cost < MCF_EDGE_COST_THR, forbidden otherwise; the private column costs
     arc_cost_int(THR, 1, a, 0). Pass 2, pairs (t, t+2), restricted to rows without successor and
     columns without predecessor after pass 1. Chains are numbered by (first frame, index).
+    images: per detection frame the image feature_model sees; needed iff MCF_VIS_SIM_WEIGHT > 0 (the transition cost then
+    carries the appearance term exactly as in build_flow_graph).
     Returns the list of trajectories [(frame, idx), ...] in id order."""
     from scipy.optimize import linear_sum_assignment
     counts = [len(d[0]) for d in dets]
     offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
     F = len(dets)
     thr = P['MCF_EDGE_COST_THR']
+    vis_w = P.get('MCF_VIS_SIM_WEIGHT', 0)
+    feats = [box_histograms(images[t], d[1], d[2]) for t, d in enumerate(dets)] if vis_w else None
     succ = [np.full(n, -1, np.int64) for n in counts]       # (frame offset encoded separately)
     succ_gap = [np.zeros(n, np.int64) for n in counts]
     has_pred = [np.zeros(n, bool) for n in counts]
@@ -454,7 +458,8 @@ def hungarian_assoc(dets, H, W, P=DEFAULTS, mask=None):
         sub_s = tuple(a[rows] for a in dets[t])
         sub_d = tuple(a[cols] for a in dets[tb])
         D = path_matrix(sub_s, sub_d, H, W, mask) if len(cols) else np.zeros((len(rows), 0), np.int32)
-        c = transition_cost(D, gap, P['MCF_MISS_RATE'])
+        vs = (1 - bhattacharyya(feats[t][rows], feats[tb][cols])) if (vis_w and len(cols)) else None
+        c = transition_cost(D, gap, P['MCF_MISS_RATE'], vis_w=vis_w if len(cols) else 0, vis_sim=vs)
         n, m = len(rows), len(cols)
         M = np.full((n, m + n), np.inf)
         for i in range(n):
@@ -594,7 +599,8 @@ def inference(frames, sd, mask=None, P=DEFAULTS, name='synth', yolo=None, assoc=
     else:
         dets = detect_from_yolo(yolo, keep, P['TILESIZE'], P['NON_MAX_SUPRESSION_DIST'])
     if assoc == 'hungarian':
-        trajs = hungarian_assoc(dets, frames.shape[1], frames.shape[2], P, mask)
+        images = [frames[t + 2] for t in range(len(dets))] if P.get('MCF_VIS_SIM_WEIGHT', 0) else None
+        trajs = hungarian_assoc(dets, frames.shape[1], frames.shape[2], P, mask, images)
         tables = ided_tables(trajs, dets)
         return dict(dets=dets, yolo=yolo, D=None, trajs=trajs, total_cost=None, tables=tables,
                     ided_all=ided_dets_all(tables))

@@ -376,6 +376,27 @@ def test_inference_hungarian_mode_end_to_end(weights):
         assert list(tabs[f].anchor_x) == [r[2] for r in rows]
 
 
+def test_inference_hungarian_mode_with_the_appearance_term(weights):
+    """ASSOCIATION='hungarian' with MCF_VIS_SIM_WEIGHT > 0 (axt_hungarian_pairs_costs): the link costs are the flow
+    tracker's arc costs with the appearance term (axt_build_arcs_vis), handed to the pair kernels as a table. Same
+    trajectories and IDed_dets_all as the oracle (SciPy LSAP on transition_cost(..., vis_w, vis_sim)), on the all-ones mask
+    and on a masked grid; and a different association from the one without the term."""
+    import axtrack_amd
+    frames = synth.synth_frames(9, 512, 512, seed=33) * np.float32(0.5)
+    model = axtrack_amd.Detector(weights, max_batch=8)
+    for mask in (None, synth.corridor_mask(512, 512, width=60, pitch=160)):
+        P = dict(params.load_parameters(), ASSOCIATION='hungarian', MCF_VIS_SIM_WEIGHT=0.3)
+        tl = axtrack_amd.Timelapse(frames, name='synth', mask=mask)
+        ad = axtrack_amd.inference(tl, model, None, P, None, None, None)
+        yolo = list(ad._yolo.cpu().numpy())
+        ref = orc.inference(frames, weights, mask=mask, P=dict(orc.DEFAULTS, MCF_VIS_SIM_WEIGHT=0.3), yolo=yolo, assoc='hungarian')
+        got = tracks_from_next(np.zeros(len(ad._track_flat)), ad._track_flat, ad._offs)
+        assert got == ref['trajs'] and ad.n_ids == len(ref['trajs'])
+        assert np.array_equal(np.nan_to_num(ad.IDed_dets_all.to_numpy(), nan=-1), np.nan_to_num(ref['ided_all'][3], nan=-1))
+        ref0 = orc.inference(frames, weights, mask=mask, P=orc.DEFAULTS, yolo=yolo, assoc='hungarian')
+        assert ref0['trajs'] != ref['trajs']
+
+
 def test_inference_hungarian_mode_on_a_masked_grid(weights):
     """The frame-to-frame variant with path lengths from the masked-grid searches (axt_hungarian_pairs_grid): the
     oracle's trajectories, which differ from those on the all-ones mask."""
