@@ -598,27 +598,32 @@ class AxonDetections(object):
         varying = self.dataset.mask3d is not None
         shard = getattr(self, '_shard', None)           # set by gather_detections(): solve only this rank's frame pairs
         if mode == 'hungarian':
-            if varying:
-                raise NotImplementedError("a time-varying mask is implemented for ASSOCIATION='mcf' (the reference's tracker) only")
             ctab = None
-            if vis_w:
+            if vis_w or varying:
                 # the appearance term: the link costs are those of the flow tracker's arcs (axt_build_arcs_vis: the same
                 # admission, the same integers), scattered into a dense table per frame pair
-                hist, hsum = self._appearance()
-                vis = dict(hist=hist, hsum=hsum, weight=vis_w, miss_rate=P['MCF_MISS_RATE'], thr=P['MCF_EDGE_COST_THR'])
+                # (likewise a mask that changes over time: one pass of the arc builder per distinct mask)
+                vis = None
+                if vis_w:
+                    hist, hsum = self._appearance()
+                    vis = dict(hist=hist, hsum=hsum, weight=vis_w, miss_rate=P['MCF_MISS_RATE'], thr=P['MCF_EDGE_COST_THR'])
                 len_table = None
                 if masked and max(dmax) - 1 > 250:       # beyond the hot-path search window: the exact lengths (as for 'mcf')
                     len_table = self._length_table_from_dists(self.astar_dists())
-                row_ptr, col, _, gap, cost = hp.build_arcs(self.d_x, self.d_y, self.d_count, self.dataset.sizey,
-                                                           self.dataset.sizex, dmax, units, self._mask_dev(),
-                                                           self.max_px_assoc_dist, self.conn8, vis, len_table, None)
+                if varying and len_table is None:
+                    row_ptr, col, _, gap, cost = self._build_arcs_time_varying(dmax, units, vis, None)
+                else:
+                    row_ptr, col, _, gap, cost = hp.build_arcs(self.d_x, self.d_y, self.d_count, self.dataset.sizey,
+                                                               self.dataset.sizex, dmax, units,
+                                                               None if varying else self._mask_dev(),
+                                                               self.max_px_assoc_dist, self.conn8, vis, len_table, None)
                 ctab = self._hungarian_cost_table(row_ptr, col, gap, cost, len(dmax))
             track, n_tracks = hp.hungarian_assoc(self.d_x, self.d_y, self.d_count, self.dataset.sizey,
                                                  self.dataset.sizex, dmax, units,
                                                  int(np.rint(P['MCF_EDGE_COST_THR'] * 1e6)),
                                                  self.max_px_assoc_dist, self.conn8,
                                                  *(((shard[0], shard[1]), shard[2]) if shard else (None, None)),
-                                                 mask=self._mask_dev() if masked else None, ctab=ctab)
+                                                 mask=self._mask_dev() if (masked and ctab is None) else None, ctab=ctab)
             self._d_track, self._track_flat_cache = track, None       # host copies are made on first use only
             self.n_ids, self.mcf_total_cost = int(n_tracks.item()), None
             return True

@@ -457,7 +457,8 @@ def hungarian_assoc(dets, H, W, P=DEFAULTS, mask=None, images=None):
             return
         sub_s = tuple(a[rows] for a in dets[t])
         sub_d = tuple(a[cols] for a in dets[tb])
-        D = path_matrix(sub_s, sub_d, H, W, mask) if len(cols) else np.zeros((len(rows), 0), np.int32)
+        m_pair = mask_of_frame(mask, tb, P.get('REPRODUCE_MASK_FRAME_QUIRK', True))        # the mask of the pair's later frame
+        D = path_matrix(sub_s, sub_d, H, W, m_pair) if len(cols) else np.zeros((len(rows), 0), np.int32)
         vs = (1 - bhattacharyya(feats[t][rows], feats[tb][cols])) if (vis_w and len(cols)) else None
         c = transition_cost(D, gap, P['MCF_MISS_RATE'], vis_w=vis_w if len(cols) else 0, vis_sim=vs)
         n, m = len(rows), len(cols)

@@ -1273,7 +1273,7 @@ def test_inference_with_a_mask_that_changes_over_time(weights, quirk):
     frame -- indexed with the detection-frame number, which is the mask of the input frame two steps earlier
     (AxonDetections.py:557,587-598; reproduced by default, REPRODUCE_MASK_FRAME_QUIRK=False uses the centre frame). Three
     masks over 13 input frames (corridors, shifted corridors, all ones): arcs, optimum and path matrices equal the
-    oracle's."""
+    oracle's; so do the trajectories of the frame-to-frame variant."""
     import axtrack_amd
     T_all = 13
     frames = synth.synth_frames(T_all, 512, 512, seed=31)
@@ -1298,8 +1298,11 @@ def test_inference_with_a_mask_that_changes_over_time(weights, quirk):
     # a [T,H,W] mask that never changes is a static mask
     tl2 = axtrack_amd.Timelapse(frames, name='synth', mask=np.stack([m0] * T_all))
     assert tl2.mask3d is None and np.array_equal(tl2.mask2d, m0)
-    with pytest.raises(NotImplementedError):
-        axtrack_amd.inference(tl, model, None, dict(P, ASSOCIATION='hungarian'), None, None, None)
+    # the frame-to-frame variant under the same masks (link costs from the per-mask passes of the arc builder)
+    adh = axtrack_amd.inference(tl, model, None, dict(P, ASSOCIATION='hungarian'), None, None, None)
+    refh = orc.inference(frames, weights, mask=mask, P=dict(orc.DEFAULTS, REPRODUCE_MASK_FRAME_QUIRK=quirk), yolo=list(yolo),
+                         assoc='hungarian')
+    assert tracks_from_next(np.zeros(len(adh._track_flat)), adh._track_flat, adh._offs) == refh['trajs']
     with pytest.raises(ValueError):
         axtrack_amd.Timelapse(frames, name='synth', mask=mask[:5])
 
