@@ -147,3 +147,66 @@ def corridor_mask(H, W, width=40, pitch=128):
     y = (np.arange(H) % pitch) < width
     x = (np.arange(W) % pitch) < width
     return (y[:, None] | x[None, :])
+
+
+def synth_detections(n_frames, H, W, n_alive=75, seed=0, mean_life=120, p_detect=0.92, clutter=0.08, max_step=10.0,
+                     jitter=2.0, min_dist=23, cap=None):
+    """Detections of a scene of MOVING growth cones, for association-only workloads (random walk of
+    <= max_step px per frame, births and deaths) -- what the detector's output looks like on real timelapses, where the
+    random-init benchmark weights give a static scene. About `n_alive` cones are alive in every frame; a cone lives
+    ~mean_life frames (geometric), moves by a momentum random walk (reflecting at the borders), is missed with
+    probability 1 - p_detect, is reported with +-jitter px of localisation noise and a confidence around its own level
+    in [0.62, 1.05] (+-0.05; below the 0.55 floor = missed); `clutter` x n_alive false detections per frame with
+    confidence in [0.55, 0.7). Every frame then goes through the detector's own greedy NMS rule (descending confidence,
+    dx^2+dy^2 < min_dist^2 suppressed; AxonDetections.py:250-278) and is ordered by descending confidence.
+
+    Returns dict(conf f32 [F,cap], x i32 [F,cap], y i32 [F,cap], count i32 [F], truth i32 [F,cap] (cone id, -1 = clutter)).
+    Deterministic in (arguments, seed): raw PCG64 streams only."""
+    F = int(n_frames)
+    s = int(seed) * 15485863 + 11
+    # cones: the initial population with random remaining lives, then births at the rate that keeps n_alive
+    births = np.floor(uniform01(s + 1, (F,)) + n_alive / float(mean_life)).astype(np.int64)       # per frame, mean n_alive/mean_life
+    births[0] = n_alive
+    n_cones = int(births.sum())
+    t_birth = np.repeat(np.arange(F), births)
+    life = np.ceil(-np.log(1.0 - uniform01(s + 2, (n_cones,))) * mean_life).astype(np.int64).clip(1)
+    level = 0.62 + 0.43 * uniform01(s + 3, (n_cones,))
+    pos0 = uniform01(s + 4, (n_cones, 2)) * np.array([W - 1.0, H - 1.0])
+    vel0 = (uniform01(s + 5, (n_cones, 2)) * 2 - 1) * max_step * 0.5
+    cap = int(cap or max(64, -(-int(n_alive * (1.6 + clutter)) // 64) * 64))
+    conf = np.zeros((F, cap), np.float32); x = np.zeros((F, cap), np.int32); y = np.zeros((F, cap), np.int32)
+    truth = np.full((F, cap), -1, np.int32); count = np.zeros(F, np.int32)
+    pos = pos0.copy(); vel = vel0.copy()
+    lim = np.array([W - 1.0, H - 1.0])
+    for t in range(F):
+        alive = np.nonzero((t_birth <= t) & (t < t_birth + life))[0]
+        u = uniform01(s + 100 + 7 * t, (n_cones, 6))
+        # momentum random walk, speed capped at max_step px per frame (per axis), reflecting borders
+        vel[alive] = np.clip(0.8 * vel[alive] + (u[alive, 0:2] * 2 - 1) * max_step * 0.4, -max_step, max_step)
+        p = pos[alive] + vel[alive]
+        over, under = p > lim, p < 0
+        p = np.where(over, 2 * lim - p, np.where(under, -p, p))
+        vel[alive] = np.where(over | under, -vel[alive], vel[alive])
+        pos[alive] = p
+        c = level[alive] + (u[alive, 2] - 0.5) * 0.1
+        seen = (u[alive, 3] < p_detect) & (c >= 0.55)
+        px = np.rint(p[seen, 0] + (u[alive, 4][seen] * 2 - 1) * jitter).clip(0, W - 1)
+        py = np.rint(p[seen, 1] + (u[alive, 5][seen] * 2 - 1) * jitter).clip(0, H - 1)
+        ids = alive[seen]
+        nc = int(np.floor(uniform01(s + 101 + 7 * t, (1,))[0] + clutter * n_alive))
+        uc = uniform01(s + 102 + 7 * t, (max(nc, 1), 3))[:nc]
+        cc = np.concatenate([c[seen], 0.55 + 0.15 * uc[:, 0]]).astype(np.float32)
+        cx = np.concatenate([px, np.floor(uc[:, 1] * W)]).astype(np.int64)
+        cy = np.concatenate([py, np.floor(uc[:, 2] * H)]).astype(np.int64)
+        ci = np.concatenate([ids, np.full(nc, -1)]).astype(np.int64)
+        order = np.argsort(-cc, kind='stable')
+        cc, cx, cy, ci = cc[order], cx[order], cy[order], ci[order]
+        d2 = (cx[:, None] - cx[None]) ** 2 + (cy[:, None] - cy[None]) ** 2 < min_dist * min_dist
+        keep = np.ones(len(cc), bool)
+        for i in range(len(cc)):                               # greedy: a kept detection suppresses every later close one
+            if keep[i]:
+                keep[i + 1:] &= ~d2[i, i + 1:]
+        n = min(int(keep.sum()), cap)
+        count[t] = n
+        conf[t, :n], x[t, :n], y[t, :n], truth[t, :n] = cc[keep][:n], cx[keep][:n], cy[keep][:n], ci[keep][:n]
+    return dict(conf=conf, x=x, y=y, count=count, truth=truth)

@@ -29,7 +29,6 @@ import sys
 import time
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -61,13 +60,32 @@ def main():
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='gloo only for rehearsals')
     ap.add_argument('--single-device', action='store_true',
                     help='rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)')
+    ap.add_argument('--launch-check', action='store_true',
+                    help='no GPU work: every rank joins a gloo group, one all-reduce, rank 0 prints what it saw (tests the launcher)')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # a bare `python bench.py --gpus N`: this process becomes the launcher of N ranks (it never touches the GPU)
+        raise SystemExit(launch_ranks(args.gpus))
+    global torch
+    import torch
 
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+    if args.launch_check:
+        import torch.distributed as dist
+        dist.init_process_group('gloo')
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({'launch_check': True, 'world': dist.get_world_size(), 'rank_sum': int(t.item()),
+                              'master': f"{os.environ['MASTER_ADDR']}:{os.environ['MASTER_PORT']}"}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if args.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -289,6 +307,43 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher's environment: start the N ranks as CHILD processes of this one
+    (same command line; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment, exactly what
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` sets), pass rank 0's JSON line through and return
+    non-zero if any rank fails. The parent initialises neither torch nor the GPU, and nothing is exec'ed."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        for line in procs[0].stdout:                    # rank 0 prints the one JSON line; library chatter goes to stderr
+            out = sys.stdout if line.lstrip().startswith(b'{') else sys.stderr
+            out.buffer.write(line)
+            out.flush()
+        for r, p in enumerate(procs):
+            code = p.wait()
+            if code != 0:
+                print(f'bench.py: rank {r} exited with code {code}', file=sys.stderr)
+                rc = rc or (code if code > 0 else 1)
+    finally:
+        for p in procs:                                 # a rank that failed leaves the others waiting in a collective
+            if p.poll() is None:
+                if rc == 0:
+                    p.wait()
+                else:
+                    p.kill()
+    return rc
 
 
 def verify(args, ad, frames_host, sd, per_rank, world):

@@ -63,42 +63,57 @@ def tracks_from_next(nxt, track, offs):
     return [sorted(out[i]) for i in sorted(out)]
 
 
-def c3_network():
-    """The flow network of the config-3 bench timelapse (252 frames, 19 340 detections captured from the GPU path into
-    tests/data/c3_dets.npz): (obs, entry, exit i64 [n], row_ptr i64 [n+1], col i32, cost i64, offs, dets)."""
+def open_grid_network(count, x, y, conf, H, W, P=None):
+    """The flow network of a set of detections on an all-ones mask, built on the CPU exactly as axt_build_arcs + the
+    host side of assign_ids build it: (obs, entry, exit i64 [n], row_ptr i64 [n+1], col i32, cost i64, offs, dets)."""
     from axtrack_amd import params
     from axtrack_amd.detections import transition_cost_table, _arc_cost_int_vec
-    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    d = np.load(os.path.join(ROOT, 'tests', 'data', 'c3_dets.npz'))
-    cnt = d['count']
+    P = P or params.DEPLOYED
+    cnt = np.asarray(count)
     F = len(cnt)
-    X = [d['x'][t, :cnt[t]].astype(np.int64) for t in range(F)]
-    Y = [d['y'][t, :cnt[t]].astype(np.int64) for t in range(F)]
-    table, dmax = transition_cost_table(params.DEPLOYED)
+    X = [x[t, :cnt[t]].astype(np.int64) for t in range(F)]
+    Y = [y[t, :cnt[t]].astype(np.int64) for t in range(F)]
+    table, dmax = transition_cost_table(P)
     offs = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
     tails, heads, gaps, lens = [], [], [], []
     for t in range(F):
-        inb_a = (X[t] >= 0) & (X[t] < 512) & (Y[t] >= 0) & (Y[t] < 512)
-        for g in (1, 2):
+        inb_a = (X[t] >= 0) & (X[t] < W) & (Y[t] >= 0) & (Y[t] < H)
+        for g in range(1, len(dmax) + 1):
             tb = t + g
             if tb >= F:
                 continue
             dx = np.abs(X[t][:, None] - X[tb][None]); dy = np.abs(Y[t][:, None] - Y[tb][None])
-            inb = inb_a[:, None] & ((X[tb] >= 0) & (X[tb] < 512) & (Y[tb] >= 0) & (Y[tb] < 512))[None]
+            inb = inb_a[:, None] & ((X[tb] >= 0) & (X[tb] < W) & (Y[tb] >= 0) & (Y[tb] < H))[None]
             D = dx + dy + 1
             i, j = np.nonzero((D <= dmax[g - 1]) & (dx * dx + dy * dy < 250000) & inb)
             tails.append(offs[t] + i); heads.append(offs[tb] + j); gaps.append(np.full(len(i), g)); lens.append(D[i, j])
     a, b, g, L = (np.concatenate(v) for v in (tails, heads, gaps, lens))
     order = np.lexsort((b, g, a))
     a, b, g, L = a[order], b[order], g[order], L[order]
-    cost = _arc_cost_int_vec(np.where(g == 1, table[0][L], table[1][L]), 3, a, b)
+    cost = _arc_cost_int_vec(table[g - 1, L], 3, a, b)
     n = int(offs[-1])
     row_ptr = np.zeros(n + 1, np.int64)
     row_ptr[1:] = np.cumsum(np.bincount(a, minlength=n))
-    conf = np.concatenate([d['conf'][t, :cnt[t]] for t in range(F)]).astype(np.float64)
-    obs = orc.observation_cost(orc.cap_conf(conf))
+    cf = np.concatenate([conf[t, :cnt[t]] for t in range(F)]).astype(np.float64)
+    obs = orc.observation_cost(orc.cap_conf(cf, P['MCF_CONF_CAPPING_METHOD']), P['MCF_MAX_CONF_COST'])
     k = np.arange(n)
-    obs_i, en_i, ex_i = (_arc_cost_int_vec(obs, 2, k, 0), _arc_cost_int_vec(np.full(n, 2.0), 0, k, 0),
-                         _arc_cost_int_vec(np.full(n, 2.0), 1, k, 0))
-    dets = [(d['conf'][t, :cnt[t]], X[t], Y[t]) for t in range(F)]
+    ee = float(P['MCF_ENTRY_EXIT_COST'])
+    obs_i, en_i, ex_i = (_arc_cost_int_vec(obs, 2, k, 0), _arc_cost_int_vec(np.full(n, ee), 0, k, 0),
+                         _arc_cost_int_vec(np.full(n, ee), 1, k, 0))
+    dets = [(conf[t, :cnt[t]], X[t], Y[t]) for t in range(F)]
     return obs_i, en_i, ex_i, row_ptr, b.astype(np.int32), cost, offs, dets
+
+
+def c3_network():
+    """The flow network of the config-3 bench timelapse (252 frames, 19 340 detections captured from the GPU path into
+    tests/data/c3_dets.npz): (obs, entry, exit i64 [n], row_ptr i64 [n+1], col i32, cost i64, offs, dets)."""
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = np.load(os.path.join(ROOT, 'tests', 'data', 'c3_dets.npz'))
+    return open_grid_network(d['count'], d['x'], d['y'], d['conf'], 512, 512)
+
+
+def moving_network(n_frames, size, n_alive, seed=0, **kw):
+    """The flow network of a scene of moving growth cones (synth.synth_detections): association-only workloads."""
+    from axtrack_amd import synth
+    d = synth.synth_detections(n_frames, size, size, n_alive=n_alive, seed=seed, **kw)
+    return open_grid_network(d['count'], d['x'], d['y'], d['conf'], size, size)

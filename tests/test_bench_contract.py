@@ -33,3 +33,34 @@ def test_rocprof_summary_agrees_with_the_bench_line():
     assert abs(float(dom['avg_us']) / 1e3 - b['roofline']['avg_launch_ms']) / b['roofline']['avg_launch_ms'] < 0.08
     t = json.load(open(os.path.join(ROOT, 'profiles', 'r01_k_traffic.json')))
     assert abs(t['hbm_bytes_per_launch'] - b['roofline']['traffic']) / t['hbm_bytes_per_launch'] < 0.01
+
+
+def _bench(*argv, env=None):
+    import subprocess
+    import sys
+    e = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *argv], env=e, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, text=True, timeout=300)
+
+
+def test_bare_invocation_with_several_gpus_starts_its_own_ranks():
+    """`python bench.py --gpus N` without a launcher's environment (the driver's command) starts N child ranks that
+    find each other on 127.0.0.1; rank 0's JSON line is the only thing on stdout."""
+    r = _bench('--gpus', '3', '--launch-check')
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    got = json.loads(lines[0])
+    assert got['world'] == 3 and got['rank_sum'] == 6 and got['master'].startswith('127.0.0.1:')
+
+
+def test_a_failing_rank_fails_the_launcher():
+    """Without a GPU the ranks of a real run die at torch.cuda.set_device: the launcher must report that, not hang or
+    exit 0 (on the GPU box the same command runs the 2-rank rehearsal: tests/test_gpu_parity.py)."""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip('the ranks would run')
+    r = _bench('--gpus', '2', '--backend', 'gloo', '--single-device', '--steps', '1', '--warmup', '0')
+    assert r.returncode != 0 and 'exited with code' in r.stderr and not r.stdout.strip()
