@@ -55,8 +55,6 @@ SIGNATURES = {
                                    c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_int64), c_void_p]),
     'axt_mcf_solve': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                               c_void_p, c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int64)]),
-    'axt_mcf_solve_dag': (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                  c_void_p, c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int64)]),
     'axt_hungarian_assoc': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                     c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     'axt_hungarian_pairs': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

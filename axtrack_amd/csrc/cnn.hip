@@ -812,6 +812,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino(const float *__restrict__
                                                        int H, int B)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    // INVARIANT: the two halves of the workgroup run different instantiations of wino_body and meet at the SAME hardware
+    // barrier (s_barrier counts arriving waves, not program counters). That only works while both instantiations execute
+    // exactly the same number of barriers: one per step() -- the step count depends on the tile range and CIN alone, never
+    // on NB or XFORM -- plus the fixed ones of the prologue. Anything that adds a barrier to one half only (an extra
+    // __syncthreads() under `if (XFORM)`, an early return) hangs the workgroup or races on LDS.
     if ((threadIdx.x >> 8) == 0) wino_body<CIN, POOL, 2, true, NG>(in, upk, bias, out, H, B, smem);
     else wino_body<CIN, POOL, 3, false, NG>(in, upk, bias, out, H, B, smem);
 }

@@ -30,6 +30,8 @@
 #include <time.h>
 
 #include <algorithm>
+#include <atomic>
+#include <memory>
 #include <mutex>
 #include <queue>
 #include <thread>
@@ -216,8 +218,18 @@ struct Lsap {
         const int64_t whole = ((entry[k] + exitc[k]) >> 16) / 5 * 4;      // four fifths of entry + exit, in whole cost units
         return whole > 0 ? whole << 16 : 0;
     }
-    size_t stat_rows = 0, stat_relax = 0, stat_push = 0;
+    size_t stat_rows = 0, stat_relax = 0, stat_push = 0, stat_died = 0;
     std::mutex stat_lock;
+    // Concurrent insertions on SHARED rows and columns (the second phase; Search::insert_row with a ticket): a search
+    // claims every column record before it reads it (a row is only ever reached through its matched column, so the
+    // column's claim covers the row), keeps its claims until its duals and its augmentation are written, and lets go.
+    // Two searches that never meet run side by side; when they meet, the older one (smaller ticket) waits for the
+    // record and the younger one gives up everything it holds and starts again ("wait-die": nobody waits for an older
+    // search, so there is no cycle, and the oldest search always finishes). Every search therefore sees the state some
+    // serial order of the insertions would have shown it; row insertion reaches the one optimum in ANY order, so the
+    // result does not depend on the interleaving.
+    std::unique_ptr<std::atomic<int32_t>[]> owner;        // per column: 0 = free, else the ticket of the holder
+    std::atomic<uint32_t> next_stamp{0};
 
     typedef std::pair<int64_t, int32_t> Item;
     // One thread's search state. Several of them work on the shared rows / columns at the same time, on index ranges
@@ -227,12 +239,48 @@ struct Lsap {
     std::vector<int32_t> sr_rows, sc_cols;
     std::vector<Item> heap;                           // min-heap of (key, column), storage reused
     uint32_t search;                                  // stamps above every stamp already left in this task's columns
-    size_t stat_rows = 0, stat_relax = 0, stat_push = 0;
+    size_t stat_rows = 0, stat_relax = 0, stat_push = 0, stat_died = 0;
+    int32_t ticket = 0;                               // > 0: concurrent mode (claims), smaller = older
+    std::vector<int32_t> claimed;
+    int32_t blocked_col = -1, blocked_by = 0;         // the claim that made this search give up
     Search(Lsap &l, uint32_t first) : L(l), search(first) {}
     ~Search()
     {
         std::lock_guard<std::mutex> g(L.stat_lock);
-        L.stat_rows += stat_rows; L.stat_relax += stat_relax; L.stat_push += stat_push;
+        L.stat_rows += stat_rows; L.stat_relax += stat_relax; L.stat_push += stat_push; L.stat_died += stat_died;
+    }
+    // Claim column j for this search. false: an older search holds it -- this one has to give up.
+    inline bool claim(int j)
+    {
+        std::atomic<int32_t> &o = L.owner[j];
+        int32_t cur = o.load(std::memory_order_relaxed);
+        if (cur == ticket) return true;
+        for (;;) {
+            if (cur == 0) {
+                if (o.compare_exchange_weak(cur, ticket, std::memory_order_acq_rel, std::memory_order_relaxed)) {
+                    claimed.push_back(j);
+                    return true;
+                }
+                continue;
+            }
+            if (cur < ticket) { blocked_col = j; blocked_by = cur; return false; }
+            __builtin_ia32_pause();                    // a younger search holds it: it will finish or give up
+            cur = o.load(std::memory_order_acquire);
+        }
+    }
+    inline bool try_claim(int j)                       // no waiting, no giving up (after the augmentation)
+    {
+        std::atomic<int32_t> &o = L.owner[j];
+        int32_t cur = o.load(std::memory_order_relaxed);
+        if (cur == ticket) return true;
+        if (cur != 0 || !o.compare_exchange_strong(cur, ticket, std::memory_order_acq_rel, std::memory_order_relaxed)) return false;
+        claimed.push_back(j);
+        return true;
+    }
+    void release()
+    {
+        for (int32_t j : claimed) L.owner[j].store(0, std::memory_order_release);
+        claimed.clear();
     }
     // 4-ary min-heap with lazy deletion (stale entries are skipped when popped)
     void heap_push(Item it)
@@ -270,14 +318,18 @@ struct Lsap {
         return top;
     }
 
-    void insert_row(int i)
+    // false (concurrent mode only): the search met an older one and gave up; nothing was changed, insert the row again
+    bool insert_row(int i)
     {
         std::vector<Col> &c = L.c;
         std::vector<Row> &rw = L.rw;
         const std::vector<Arc> &arcs = L.arcs;
         const int n = L.n;
         heap.clear();
-        search += 2;
+        const bool par = ticket > 0;
+        bool dead = false;
+        if (par) search = L.next_stamp.fetch_add(2, std::memory_order_relaxed);
+        else search += 2;
         const uint32_t open = search, closed = search + 1;
         int64_t minVal = 0;
         int64_t best_free = INF;          // shortest distance to a FREE column seen so far: nothing at or beyond it
@@ -289,6 +341,7 @@ struct Lsap {
             const Row &rc = rw[cur];
             const int64_t off = minVal - rc.u;
             auto relax = [&](int j, int64_t w, int32_t arc) {
+                if (par && !claim(j)) { dead = true; return; }
                 Col &cj = c[j];
                 ++stat_relax;
                 if (cj.stamp == closed) return;
@@ -305,7 +358,8 @@ struct Lsap {
                 }
             };
             relax(cur, 0, -1);                  // stay unused
-            relax(n + cur, rc.own, -1);         // a track of its own / track end
+            if (!dead) relax(n + cur, rc.own, -1);         // a track of its own / track end
+            if (dead) { release(); ++stat_died; return false; }
             // arcs sorted by cost: column duals are <= 0, so once the bare cost reaches best_free the rest cannot matter
             const Arc *ap = arcs.data() + rc.arc_begin;
             // the column records are visited in arc order, i.e. at random: ask for them a few arcs ahead
@@ -315,7 +369,9 @@ struct Lsap {
                 if (off + w >= best_free) break;
                 if (k + 6 < rc.degree) __builtin_prefetch(&c[ap[k + 6].head]);
                 relax(ap[k].head, w, ap[k].id);
+                if (dead) break;
             }
+            if (dead) { release(); ++stat_died; return false; }
             int j = -1;
             while (!heap.empty()) {
                 const Item it = heap_pop();
@@ -361,7 +417,10 @@ struct Lsap {
             Row &rr = rw[r];
             const int m = rr.col;
             int64_t best2 = INF, cm = 0;
+            bool all = true;
             auto see = [&](int j, int64_t w) {
+                if (par && all && !try_claim(j)) all = false;       // somebody else is at that column: leave this row's duals as they are
+                if (!all) return;
                 if (j == m) cm = w;
                 else { const int64_t k = w - c[j].v; if (k < best2) best2 = k; }
             };
@@ -369,10 +428,12 @@ struct Lsap {
             see(n + r, rr.own);
             const Arc *ap = arcs.data() + rr.arc_begin;
             for (int k = 0; k < rr.degree; ++k) see(ap[k].head, rr.base + ap[k].w);
-            if (best2 < INF && best2 > rr.u) { rr.u = best2; c[m].v = cm - best2; }
+            if (all && best2 < INF && best2 > rr.u) { rr.u = best2; c[m].v = cm - best2; }
         };
         if (sr_rows.size() > 8) for (int32_t r : sr_rows) transfer(r);
         else transfer(i);
+        if (par) release();
+        return true;
     }
 
     // rows in a fixed pseudo-random order (xorshift64 seeded by the first row: the same at any thread count)
@@ -391,6 +452,44 @@ struct Lsap {
         for (int i = 0; i < m; ++i) insert_row(order[i]);
     }
     };  // struct Search
+
+    // Insert `rows` (in this order of seniority) on `threads` host threads that share every row and column.
+    void insert_concurrently(const std::vector<int32_t> &rows, int threads)
+    {
+        if (rows.empty()) return;
+        if (threads > (int)rows.size()) threads = (int)rows.size();
+        if (threads <= 1) {
+            Search w(*this, next_stamp.load());
+            for (int32_t k : rows) w.insert_row(k);
+            next_stamp.store(w.search + 2);
+            return;
+        }
+        if (!owner) {
+            owner.reset(new std::atomic<int32_t>[2 * (size_t)n]);
+            for (size_t j = 0; j < 2 * (size_t)n; ++j) owner[j].store(0, std::memory_order_relaxed);
+        }
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            Search w(*this, 0);
+            for (;;) {
+                const size_t q = next.fetch_add(1, std::memory_order_relaxed);
+                if (q >= rows.size()) break;
+                w.ticket = (int32_t)q + 1;
+                while (!w.insert_row(rows[q])) {
+                    // start again once the older search that was in the way has let go of that column
+                    int spins = 0;
+                    while (owner[w.blocked_col].load(std::memory_order_acquire) == w.blocked_by)
+                        if (++spins > 64) { std::this_thread::yield(); spins = 0; } else __builtin_ia32_pause();
+                }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < threads; ++t) {
+            try { pool.emplace_back(work); } catch (...) { break; }
+        }
+        work();
+        for (std::thread &t : pool) t.join();
+    }
 
     // ---- time blocks ---------------------------------------------------------------------------------------
     // Row k only reaches columns R_k, X_k and R_b of its successors b > k, all within reach[k] = max b. Cut the rows at
@@ -521,15 +620,30 @@ struct Lsap {
             }
             two_phase = false;
             for (int32_t k : again) { c[n + k].row = -1; c[n + k].v = 0; rw[k].col = -1; rw[k].arc = -1; rw[k].u = 0; }
-            Search w(*this, 0x7f000000u);
-            for (int32_t k : again) w.insert_row(k);
+            next_stamp.store(0x7f000000u);
+            // side by side only where the searches have room to miss each other: on config 3's 19 k detections every
+            // search covers a sixth of the timelapse and the younger ones would mostly wait
+            int par = n >= 50000 ? budget : 1;
+            if (const char *e = getenv("AXT_MCF_ENDS_THREADS")) par = atoi(e) >= 1 ? atoi(e) : 1;
+            if (par > 1) {
+                // searches that run side by side should be far apart in time: deal the ends (which are in time order) so
+                // that consecutive tickets come from `par` different stretches of the timelapse
+                std::vector<int32_t> dealt;
+                dealt.reserve(again.size());
+                const size_t per = (again.size() + par - 1) / par;
+                for (size_t q = 0; q < per; ++q)
+                    for (int t = 0; t < par; ++t)
+                        if (t * per + q < again.size() && t * per + q < (t + 1) * per) dealt.push_back(again[t * per + q]);
+                again.swap(dealt);
+            }
+            insert_concurrently(again, par);
             ends = again.size();
         }
         if (getenv("AXT_MCF_DEBUG"))
             fprintf(stderr, "lsap: second phase %zu track ends, %.1f ms; ", ends, now_ms() - t2);
         if (getenv("AXT_MCF_DEBUG"))
-            fprintf(stderr, "lsap: n=%d threads<=%d leaves=%d rows scanned=%zu relax=%zu push=%zu  setup %.1f ms, insertions %.1f ms\n", n,
-                    budget, leaves, stat_rows, stat_relax, stat_push, t1 - t0, now_ms() - t1);
+            fprintf(stderr, "lsap: n=%d threads<=%d leaves=%d rows scanned=%zu relax=%zu push=%zu gave up=%zu  setup %.1f ms, insertions %.1f ms\n", n,
+                    budget, leaves, stat_rows, stat_relax, stat_push, stat_died, t1 - t0, now_ms() - t1);
     }
 };
 

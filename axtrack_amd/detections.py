@@ -52,9 +52,14 @@ class AxonDetections(object):
         self.dir = directory
         if self.dir:
             os.makedirs(self.dir, exist_ok=True)
-        if timepoint_subset is not None:
-            raise NotImplementedError('timepoint_subset is a training/evaluation feature (out of scope)')
-        self.timepoint_subset = range(self.dataset.sizet)
+        # AxonDetections.py:52-55: the detection frames to work on (default: all). Detection, association and every
+        # per-frame accessor then index POSITIONS in this list, as the reference's do (its loops run over
+        # range(len(self)) and look frames up through timepoint_subset).
+        if timepoint_subset is None:
+            timepoint_subset = range(self.dataset.sizet)
+        self.timepoint_subset = [int(t) for t in timepoint_subset]
+        if any(t < 0 or t >= self.dataset.sizet for t in self.timepoint_subset):
+            raise ValueError(f'timepoint_subset must lie in [0, {self.dataset.sizet})')
         self.P = dict(parameters)
         self.device = dataset.device
         self.Sx, self.Sy, self.tilesize = parameters['SX'], parameters['SY'], parameters['TILESIZE']
@@ -98,21 +103,33 @@ class AxonDetections(object):
             raise ValueError('the timelapse is empty (no tile has a non-zero pixel)')
         if hasattr(self.model, 'set_arith'):
             self.model.set_arith(self.P.get('CNN_ARITH', 'f32'))       # read at inference time, like every parameter
-        self._yolo = self.model.detect_frames(frames, self.tile_yx, 0, self.dataset.sizet)
+        # the frames of timepoint_subset (AxonDetections.py:111), one launch sequence per run of consecutive frames
+        sub = self.timepoint_subset
+        runs, a = [], 0
+        for k in range(1, len(sub) + 1):
+            if k == len(sub) or sub[k] != sub[k - 1] + 1:
+                runs.append((sub[a], k - a))
+                a = k
+        parts = [self.model.detect_frames(frames, self.tile_yx, t0, n) for t0, n in runs]
+        self._yolo = parts[0] if len(parts) == 1 else torch.cat(parts, 0)
+        self._tiled_tables = None
         thr = float(np.float32(self.all_conf_thrs.min()))
         self.d_conf, self.d_x, self.d_y, self.d_count = hp.decode_stitch_nms(
             self._yolo, self.tile_yx, thr, self.nms_min_dist)
         import torch.distributed as dist
         if self.d_conf.shape[1] > 2048 and not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
             # large frames (more than 14 tiles): the arrays were sized for one detection per grid cell; keep what the fullest
-            # frame needs (the arc builder's scratch and the frame-to-frame variant scale with the capacity)
-            cap = max(int(self.d_count.max().item()), 1)
-            cap = min(-(-cap // 64) * 64, int(self.d_conf.shape[1]))
-            self.d_conf, self.d_x, self.d_y = (a[:, :cap].contiguous() for a in (self.d_conf, self.d_x, self.d_y))
+            # frame needs (the arc builder's scratch and the frame-to-frame variant scale with the capacity). Frame-sharded
+            # ranks agree on a common capacity in gather_detections().
+            self._shrink_capacity(int(self.d_count.max().item()))
         self._det_tables = None
         self._host = None
         if cache == 'to':
             self.to_cache('_detections', self._detections)
+
+    def _shrink_capacity(self, fullest):
+        cap = min(-(-max(int(fullest), 1) // 64) * 64, int(self.d_conf.shape[1]))
+        self.d_conf, self.d_x, self.d_y = (a[:, :cap].contiguous() for a in (self.d_conf, self.d_x, self.d_y))
 
     def gather_detections(self, group=None):
         """Frame-sharded runs: every rank has detected its own contiguous block of frames; one
@@ -121,6 +138,13 @@ class AxonDetections(object):
         from .sharded import all_gather_detections
         import torch.distributed as dist
         local = int(self.d_count.shape[0])
+        if self.d_conf.shape[1] > 2048 and dist.is_initialized() and dist.get_world_size(group) > 1:
+            # large frames: every rank keeps what the fullest frame of the WHOLE timelapse needs (one MAX all-reduce over
+            # the group of the gather), so that the gathered arrays fit the association kernels' capacity
+            from .sharded import _collective
+            fullest = self.d_count.max().reshape(1).clone()
+            _collective('capacity_allreduce', lambda: dist.all_reduce(fullest, op=dist.ReduceOp.MAX, group=group))
+            self._shrink_capacity(int(fullest.item()))
         if self.P['MCF_VIS_SIM_WEIGHT'] and dist.is_initialized() and dist.get_world_size(group) > 1:
             # the appearance features need the pixels, which only the owning rank has: they travel with the detections
             hist, hsum = self._appearance()
@@ -177,13 +201,57 @@ class AxonDetections(object):
             self._det_tables = tabs
         return self._det_tables
 
+    @property
+    def _pandas_tiled_dets(self):
+        """_yolo_Y2pandas_det (AxonDetections.py:178-248) of every frame: per frame a list over the kept tiles of tables
+        [conf Float32, anchor_x Int64, anchor_y Int64] in TILE coordinates, the cells at or above the confidence floor
+        named Axon_000.. in cell order and sorted by ascending confidence -- the tables before stitching and NMS. The
+        hot path never needs them (its kernel goes from the YOLO grids to the frame's final list), so they are decoded
+        from the grids on the host when first asked for: f32 arithmetic, half-to-even rounding, all-zero cells left
+        at zero, exactly as :192-210."""
+        if getattr(self, '_tiled_tables', None) is None:
+            yolo = getattr(self, '_yolo', None)
+            if yolo is None:
+                raise ValueError('the tile tables come from the YOLO grids: run detect_dataset() (not from a cache)')
+            y = yolo.cpu().numpy().astype(np.float32, copy=False)            # [F, n_tiles, Sx, Sy, 3]
+            ii = np.arange(self.Sx, dtype=np.float32).reshape(1, 1, self.Sx, 1)
+            jj = np.arange(self.Sy, dtype=np.float32).reshape(1, 1, 1, self.Sy)
+            ts = np.float32(self.tilesize)
+            ax = np.rint(((y[..., 1] + ii) * ts) / np.float32(self.Sx))
+            ay = np.rint(((y[..., 2] + jj) * ts) / np.float32(self.Sy))
+            zero = (y == 0).all(-1)
+            ax[zero] = 0
+            ay[zero] = 0
+            thr = np.float32(self.all_conf_thrs.min())
+            frames = []
+            for f in range(y.shape[0]):
+                tiles = []
+                for k in range(y.shape[1]):
+                    conf = y[f, k, ..., 0].reshape(-1)
+                    keep = np.nonzero(conf >= thr)[0]
+                    order = keep[np.argsort(conf[keep], kind='stable')]       # ties stay in cell order
+                    names = np.empty(len(conf), dtype=object)
+                    names[keep] = [f'Axon_{i:0>3}' for i in range(len(keep))]
+                    tiles.append(pd.DataFrame({'conf': pd.array(conf[order], dtype='Float32'),
+                                               'anchor_x': pd.array(ax[f, k].reshape(-1)[order].astype(np.int64), dtype='Int64'),
+                                               'anchor_y': pd.array(ay[f, k].reshape(-1)[order].astype(np.int64), dtype='Int64')},
+                                              index=list(names[order])))
+                frames.append(tiles)
+            self._tiled_tables = frames
+        return self._tiled_tables
+
     # ------------------------------------------------------------------ access (AxonDetections.py:280-353)
     def get_frame_dets(self, which_dets, t, libmot=False, unstitched=False):
-        if unstitched:
-            raise NotImplementedError('unstitched tile tables are not kept by the HIP path')
         if t is None:
             all_dets = [self.get_frame_dets(which_dets, t, libmot) for t in range(len(self))]
             return pd.concat(all_dets, axis=not libmot)
+        if unstitched:
+            # only for 'all' and 'confident' (AxonDetections.py:322-331): the tile-wise list of tables
+            if which_dets == 'all':
+                return [d.copy() for d in self._pandas_tiled_dets[t]]
+            if which_dets == 'confident':
+                return [d[d.conf > self.conf_thr] for d in self._pandas_tiled_dets[t]]
+            raise ValueError("unstitched=True goes with which_dets 'all' or 'confident'")
         if which_dets == 'all':
             det = self._detections[t]
         elif which_dets == 'confident':
@@ -410,7 +478,11 @@ class AxonDetections(object):
         from scipy import sparse
         if self.dataset.masked:
             return self._masked_dets_paths()
-        dists = self.astar_dists()
+        return self._open_dets_paths(self.astar_dists())
+
+    def _open_dets_paths(self, dists):
+        """The paths of frame pairs on an all-ones mask (closed form): dists = {label: length matrix} of those pairs."""
+        from scipy import sparse
         cnt, _, x, y = self._host_dets()
         H, W = self.dataset.sizey, self.dataset.sizex
         out = {}
@@ -458,6 +530,12 @@ class AxonDetections(object):
                 lbl = f'{self.dataset.name}_t:{t:0>3}-t:{t_bef:0>3}'
                 if na == 0 or nb == 0:
                     out[lbl] = [[] for _ in range(na)]
+                    continue
+                if grid is None:
+                    # a frame of a time-varying mask that is all ones: the closed-form staircase of the open grid
+                    D = hp.path_cost(self.d_x[t_bef, :na], self.d_y[t_bef, :na], self.d_x[t, :nb], self.d_y[t, :nb],
+                                     H, W, None, self.max_px_assoc_dist, self.conn8).cpu().numpy()
+                    out.update(self._open_dets_paths({lbl: D}))
                     continue
                 D, cells = hp.path_cells(self.d_x[t_bef, :na], self.d_y[t_bef, :na], self.d_x[t, :nb], self.d_y[t, :nb],
                                          H, W, grid, self.max_px_assoc_dist, self.conn8)
@@ -519,7 +597,10 @@ class AxonDetections(object):
         """feature_model's histograms of every detection (device tensors hist f32 [F,cap,180], sums f64 [F,cap]),
         computed once from the centre frames (AxonDetections.py:682-685)."""
         if getattr(self, '_hist', None) is None:
-            self._hist = hp.box_histograms(self.dataset.frames, self.d_x, self.d_y, self.d_count, t_offset=2,
+            frames, off = self.dataset.frames, 2
+            if self.timepoint_subset != list(range(self.dataset.sizet)) and getattr(self, '_shard', None) is None:
+                frames, off = frames[[t + 2 for t in self.timepoint_subset]].contiguous(), 0     # the centre frames of the subset
+            self._hist = hp.box_histograms(frames, self.d_x, self.d_y, self.d_count, t_offset=off,
                                            box=self.axon_box_size)
         return self._hist
 
@@ -579,7 +660,8 @@ class AxonDetections(object):
             keep = index_d[frame_of[col.long()]] == g
             parts.append((tail[keep], col[keep], length[keep], gap_a[keep], cost[keep]))
         tail, col, length, gap_a, cost = (torch.cat([p[i] for p in parts]) for i in range(5))
-        order = torch.argsort((tail << 34) | (gap_a.long() << 32) | col.long())
+        # (tail, gap, head): gap and head get fields as wide as their ranges (a gap > 3 no longer spills into the tail)
+        order = torch.argsort((tail * (gaps + 1) + gap_a.long()) * max(n_det, 1) + col.long())
         tail, col, length, gap_a, cost = tail[order], col[order], length[order], gap_a[order], cost[order]
         row_ptr = torch.zeros(F * cap + 1, dtype=torch.int64, device=dev)
         row_ptr[1:n_det + 1] = torch.cumsum(torch.bincount(tail, minlength=n_det), 0)

@@ -467,24 +467,3 @@ def mcf_solve(obs_int, entry_int, exit_int, row_ptr, col, cost_int, min_flow, ma
     if rc == 1:
         return None
     return nxt, track, int(n_tracks.value), int(total.value)
-
-
-def mcf_solve_dag(frame_ptr, obs_int, entry_int, exit_int, row_ptr, col, cost_int, min_flow, max_flow):
-    """The flow tracker's optimum by dynamic-programming sweeps over the frames, on host arrays (axt_mcf_solve_dag: the host
-    statement of the device solver's algorithm). Same returns as mcf_solve."""
-    n = len(obs_int)
-    fp = np.ascontiguousarray(frame_ptr, np.int64)
-    arrs = [np.ascontiguousarray(a, np.int64) for a in (obs_int, entry_int, exit_int, row_ptr)]
-    col = np.ascontiguousarray(col, np.int32)
-    cost_int = np.ascontiguousarray(cost_int, np.int64)
-    nxt = np.empty(n, np.int32)
-    track = np.empty(n, np.int32)
-    n_tracks, total = ctypes.c_int(0), ctypes.c_int64(0)
-    rc = _lib.check(_lib.load().axt_mcf_solve_dag(n, len(fp) - 1, fp.ctypes.data, arrs[0].ctypes.data, arrs[1].ctypes.data,
-                                                  arrs[2].ctypes.data, arrs[3].ctypes.data, col.ctypes.data,
-                                                  cost_int.ctypes.data, int(min_flow), int(max_flow), nxt.ctypes.data,
-                                                  track.ctypes.data, ctypes.byref(n_tracks), ctypes.byref(total)),
-                    'axt_mcf_solve_dag')
-    if rc == 1:
-        return None
-    return nxt, track, int(n_tracks.value), int(total.value)

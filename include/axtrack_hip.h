@@ -277,14 +277,6 @@ int axt_mcf_solve(int n_det, const int64_t *h_obs, const int64_t *h_entry, const
                   int min_flow, int max_flow,
                   int32_t *h_next, int32_t *h_track, int *n_tracks, int64_t *total_cost);
 
-/* The same optimum by successive shortest paths computed as dynamic-programming sweeps over the frames (no priority
- * queue): the host statement of the algorithm that axt_mcf_solve_device runs on the GPU (same phases, same results).
- * h_frame_ptr i64 [n_frames+1] = first detection of every frame (detections are numbered frame-major); arcs may reach
- * any number of frames ahead. Outputs and return codes as axt_mcf_solve. */
-int axt_mcf_solve_dag(int n_det, int n_frames, const int64_t *h_frame_ptr, const int64_t *h_obs, const int64_t *h_entry,
-                      const int64_t *h_exit, const int64_t *h_row_ptr, const int32_t *h_col, const int64_t *h_cost,
-                      int min_flow, int max_flow, int32_t *h_next, int32_t *h_track, int *n_tracks, int64_t *total_cost);
-
 /* ------------------------------------------------------------------------------------------
  * Frame-to-frame Hungarian association (BASELINE config 3; a build-side variant -- the reference
  * only runs the global tracker above, AxonDetections.py:663-690). Same cost model: linking a (frame t)

