@@ -6,7 +6,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libaxtrack_hip.so')
+# AXT_LIB_PATH: a diagnostic build of the same library (profiles/wino_stamps.py); there is still no fallback
+LIB_PATH = os.environ.get('AXT_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libaxtrack_hip.so')
 
 c_void_p, c_int, c_float, c_double, c_size_t, c_int64 = (
     ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_size_t, ctypes.c_int64)

@@ -538,6 +538,26 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3(
 // ------------------------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef AXT_WINO_XFORM_PRIO
+#define AXT_WINO_XFORM_PRIO 2
+#endif
+// Diagnostic build only (-DAXT_WINO_STAMPS, profiles/wino_stamps.py): s_memtime stamps at the segment boundaries of a chunk,
+// summed per wave in scalar registers and stored once after the loop to a buffer nothing else reads.
+#ifdef AXT_WINO_STAMPS
+__device__ unsigned long long g_wino_stamps[1024 * 8 * 8];
+#define WINO_STAMP(i)                                                                                          \
+    do {                                                                                                       \
+        unsigned long long t_;                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        st_sum[i] += t_ - st_prev;                                                                             \
+        st_prev = t_;                                                                                          \
+    } while (0)
+#else
+#define WINO_STAMP(i)
+#endif
+
 struct GeoW {
     static constexpr int CCH = 8;
     static constexpr int VBUF = 16 * 4 * 64 * 2;          // floats per V buffer
@@ -618,13 +638,21 @@ __device__ __forceinline__ void wino_body(const float *__restrict__ in, const fl
     // every workgroup starts its round through a chunk's 40 pieces elsewhere: the CUs of an XCD run in step, and without
     // the rotation they all ask the L2 for the same lines at the same moment
     const int rot = (blockIdx.x * 7) % 40;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // The stream goes through a buffer descriptor that covers exactly the packed image (NG * NCH chunks): a chunk index
+    // outside it -- which the clamps of step() never produce -- would read zeros instead of leaving the allocation
+    // (the patches are range-checked the same way; round 2's experimental builds faulted on exactly such a load).
+    const __amdgpu_buffer_rsrc_t u_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(upk), 0, NG * NCH * G::UBUF * 4, 0x00020000);
+    // The U stream is issued by the waves with three channel blocks (h = 1) alone, ten pieces each: in-kernel stamps show
+    // them waiting ~3 000 cycles per chunk at the barrier for their partners, which carry the transform and the patch
+    // loads on top of their MFMAs (profiles/r03c_stamps_*.log) -- a DMA instruction costs its wave 100-400 cycles of issue.
     auto dma_piece = [&](int c, int buf, int k) {               // c: chunk index in the packed image (group * NCH + chunk)
-        int piece = wave * 5 + k + rot;
+        int piece = (wave_u & 3) * 10 + k + rot;                // k = 0 .. 9; wave-uniform: it travels in the scalar offset
         piece = piece >= 40 ? piece - 40 : piece;
-        const float *src = upk + (long)c * G::UBUF + piece * 256 + lane * 4;
         float *dst = Us + buf * G::UBUF + piece * 256;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(u_rsrc, (__attribute__((address_space(3))) void *)dst, 16,
+                                                 lane * 16, c * (G::UBUF * 4) + piece * 1024, 0, 0);
     };
     // B^T d B of the two patches in `set` -> V[buf][pos][m][lane][k-step]
     auto xform_store = [&](int set, int buf) {
@@ -643,19 +671,24 @@ __device__ __forceinline__ void wino_body(const float *__restrict__ in, const fl
                 row[r][2] = d[set][s][r][1];
                 row[r][3] = last_col ? halo : right;
             }
+            // one plain v_add / v_sub each: left to itself hipcc pairs these into v_pk_add_f32 plus the moves that line the
+            // pairs up (63 + 45 instructions per chunk), and packed f32 arithmetic is slow beside the partner wave's MFMAs --
+            // the transform took 2 100 cycles per chunk (profiles/r03e_stamps_40p.log)
+            auto fadd = [](float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+            auto fsub = [](float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
-                t[0][x] = row[0][x] - row[2][x];
-                t[1][x] = row[1][x] + row[2][x];
-                t[2][x] = row[2][x] - row[1][x];
-                t[3][x] = row[1][x] - row[3][x];
+                t[0][x] = fsub(row[0][x], row[2][x]);
+                t[1][x] = fadd(row[1][x], row[2][x]);
+                t[2][x] = fsub(row[2][x], row[1][x]);
+                t[3][x] = fsub(row[1][x], row[3][x]);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                v[s][i * 4 + 0] = t[i][0] - t[i][2];
-                v[s][i * 4 + 1] = t[i][1] + t[i][2];
-                v[s][i * 4 + 2] = t[i][2] - t[i][1];
-                v[s][i * 4 + 3] = t[i][1] - t[i][3];
+                v[s][i * 4 + 0] = fsub(t[i][0], t[i][2]);
+                v[s][i * 4 + 1] = fadd(t[i][1], t[i][2]);
+                v[s][i * 4 + 2] = fsub(t[i][2], t[i][1]);
+                v[s][i * 4 + 3] = fsub(t[i][1], t[i][3]);
             }
         }
         float *dstv = Vs + buf * G::VBUF + (m * 64 + lane) * 2;
@@ -693,15 +726,13 @@ __device__ __forceinline__ void wino_body(const float *__restrict__ in, const fl
                                                                        (FIRST && s == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[pos][n], 0, 0, 0);
             int nvm = 0;
             if constexpr (XFORM) {
-                if (pos < 8) {                          // the patches first: they come from HBM
-                    raw_load(set, pos);
+                // the patches of the chunk after next: they have until the transform at the start of the next chunk
+                if (pos >= 2 && pos < 10) {
+                    raw_load(set, pos - 2);
                     nvm = 2;
-                } else if (pos < 13) {
-                    dma_piece(c_next, buf ^ 1, pos - 8);
-                    nvm = 1;
                 }
-            } else if (pos >= 6 && pos < 11) {          // (the other waves: after the patch loads have left the address unit)
-                dma_piece(c_next, buf ^ 1, pos - 6);
+            } else if (pos >= 2 && pos < 12) {          // U of the next chunk: has to land by the end of this one
+                dma_piece(c_next, buf ^ 1, pos - 2);
                 nvm = 1;
             }
             __builtin_amdgcn_sched_group_barrier(0x100, 1 + NTW, 0);
@@ -755,41 +786,65 @@ __device__ __forceinline__ void wino_body(const float *__restrict__ in, const fl
         }
     };
 
-    // ---- prologue: patches and U of the first chunk; V of the first chunk ----
+    // ---- prologue: U and V of the first chunk; the patches of the second chunk on their way ----
     if constexpr (XFORM) {
         plan_tile(lw);
 #pragma unroll
         for (int k = 0; k < 8; ++k) raw_load(0, k);
         advance_cursor();
-    }
+        xform_store(0, 0);                                       // (waits for the patches)
 #pragma unroll
-    for (int k = 0; k < 5; ++k) dma_piece(group_of(wr.begin) * NCH, 0, k);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if constexpr (XFORM) xform_store(0, 0);
+        for (int k = 0; k < 8; ++k) raw_load(0, k);
+        advance_cursor();
+    } else {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) dma_piece(group_of(wr.begin) * NCH, 0, k);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
 
-    // ---- the chunk stream (LDS buffer = parity of the chunk count) ----
+    // ---- the chunk stream (LDS buffer = parity of the chunk count). During chunk g a transform wave first turns the
+    // patches of chunk g + 1 (fetched behind the MFMAs of chunk g - 1) into V[other buffer] -- while its partner on the
+    // SIMD, which has half again as many MFMAs per chunk, has the matrix pipe to itself -- and then joins the MFMAs of
+    // chunk g, behind which the U of chunk g + 1 (LDS-DMA into the other U buffer) and the patches of chunk g + 2 (into the
+    // registers the transform has just emptied) are issued. Nothing is left for the end of the chunk but the wait for
+    // the DMA pieces. (Round 2 transformed at the END of the chunk, after the wave's MFMAs: the partner then ran its last
+    // third of the chunk alone and every stall of its DMA issue idled the matrix pipe -- busy 0.65.)
     int w_cur = wr.begin, c = 0;
     bool done = false;
+#ifdef AXT_WINO_STAMPS
+    unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
+#endif
     auto step = [&](int PAR) {
         const bool last = c + 1 == NCH;
         // U of the chunk after this one: the next chunk of this tile's group, or the first chunk of the next tile's group
         const int w_after = w_cur + wr.step < wr.end ? w_cur + wr.step : w_cur;
         const int c_next = last ? group_of(w_after) * NCH : group_of(w_cur) * NCH + c + 1;
-        if (c == 0) mfma_chunk(std::true_type{}, PAR, 0, c_next);
-        else mfma_chunk(std::false_type{}, PAR, 0, c_next);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the patches and this wave's DMA pieces have landed
         if constexpr (XFORM) {
-            advance_cursor();
-            // the transform reads d only from here on: without this tie the compiler starts it inside the MFMA stream and
-            // waits there for loads it has just issued
+#ifdef AXT_WINO_STAMPS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            WINO_STAMP(6);
+#endif
+            // the transform is the serial head of this wave's chunk: its VALU goes ahead of the partner's MFMA stream
+            __builtin_amdgcn_s_setprio(AXT_WINO_XFORM_PRIO);
+            xform_store(0, PAR ^ 1);                              // (after the WG's last chunk: of refetched patches, unused)
+            __builtin_amdgcn_s_setprio(0);
+            // the patch registers are free from here on: without this tie the compiler may issue the next loads into them
+            // before the transform has read them all
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     asm volatile("" : "+v"(d[0][s][r][0]), "+v"(d[0][s][r][1]), "+v"(d[0][s][r][2]));
-            xform_store(0, PAR ^ 1);                                // (after the WG's last chunk: of refetched patches, unused)
         }
+        WINO_STAMP(0);
+        if (c == 0) mfma_chunk(std::true_type{}, PAR, 0, c_next);
+        else mfma_chunk(std::false_type{}, PAR, 0, c_next);
+        WINO_STAMP(1);
+        if constexpr (XFORM) advance_cursor();                    // (its patch loads stay in flight across the barrier)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces have landed
+        WINO_STAMP(2);
         if (last) {
             epilogue(w_cur);
             c = 0;
@@ -797,11 +852,19 @@ __device__ __forceinline__ void wino_body(const float *__restrict__ in, const fl
             done = w_cur >= wr.end;
             if (NG > 1 && !done) load_bias(group_of(w_cur));
         } else ++c;
+        WINO_STAMP(3);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        WINO_STAMP(4);
     };
     int g = 0;
     do step(g++ & 1);
     while (!done);
+#ifdef AXT_WINO_STAMPS
+    if (CIN == AXT_WINO_STAMP_CIN && POOL == (bool)AXT_WINO_STAMP_POOL && NG == 1 && lane == 0 && blockIdx.x < 1024) {
+        st_sum[5] = (unsigned long long)g;
+        for (int i = 0; i < 8; ++i) g_wino_stamps[(blockIdx.x * 8 + wave) * 8 + i] = st_sum[i];
+    }
+#endif
 }
 
 template <int CIN, bool POOL, int NG>
@@ -1959,3 +2022,11 @@ int axt_cnn_forward_frames(axt_detector *det, const float *d_frames, int T_all, 
 }
 
 }  // extern "C"
+
+#ifdef AXT_WINO_STAMPS
+// diagnostic build: the stamp sums of the last Winograd launch, u64 [1024 workgroups][8 waves][8]
+extern "C" int axt_debug_wino_stamps(unsigned long long *h_out)
+{
+    return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_wino_stamps), sizeof(unsigned long long) * 1024 * 8 * 8) == hipSuccess ? 0 : -1;
+}
+#endif

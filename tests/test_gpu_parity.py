@@ -1619,3 +1619,198 @@ def test_timepoint_subset_and_unstitched_tables(golden, weights):
         assert list(d.index) == [f'Axon_{i:0>3}' for i in order]
     conf_tiles = ad.get_frame_dets('confident', 2, unstitched=True)
     assert all((d.conf > ad.conf_thr).all() for d in conf_tiles)
+
+
+# ----------------------------------------------------------------------------------------- BASELINE configs at full size
+def _product_arcs(ad):
+    """The arc list assign_ids builds for this object's detections (same call, same parameters)."""
+    from axtrack_amd.detections import _cost_units_on_device
+    dmax, units = _cost_units_on_device(ad.P, ad.max_px_assoc_dist, ad.device)
+    row_ptr, col, length, gap, cost = hp.build_arcs(ad.d_x, ad.d_y, ad.d_count, ad.dataset.sizey, ad.dataset.sizex, dmax, units,
+                                                    ad._mask_dev() if ad.dataset.masked else None, ad.max_px_assoc_dist, ad.conn8)
+    return (row_ptr.cpu().numpy(), col.cpu().numpy(), length.cpu().numpy(), gap.cpu().numpy(), cost.cpu().numpy())
+
+
+def _check_arc_rows_against_oracle(ad, arcs, frames_t, sources_per_frame, mask, H, W):
+    """CSR rows of sampled source detections of sampled frames against the oracle's path lengths, admission and integer
+    costs (global numbering): returns the number of arcs compared."""
+    row_ptr, col, length, gap, cost = arcs
+    cnt, conf, x, y = ad._host_dets()
+    offs = ad._offs
+    P = orc.DEFAULTS
+    det = lambda t: (conf[t, :cnt[t]], x[t, :cnt[t]].astype(np.int64), y[t, :cnt[t]].astype(np.int64))
+    rng = np.random.default_rng(5)
+    n_arcs = 0
+    for t in frames_t:
+        pick = np.arange(cnt[t]) if sources_per_frame is None else np.sort(rng.choice(cnt[t], min(sources_per_frame, cnt[t]), replace=False))
+        src = tuple(a[pick] for a in det(t))
+        want = {int(i): [] for i in pick}
+        for g in (1, 2):
+            if t + g >= len(cnt):
+                continue
+            D = orc.path_matrix(src, det(t + g), H, W, mask)
+            c = orc.transition_cost(D, g, P['MCF_MISS_RATE'])
+            for r, j in zip(*np.nonzero(c < P['MCF_EDGE_COST_THR'])):
+                a, b = int(offs[t] + pick[r]), int(offs[t + g] + j)
+                want[int(pick[r])].append((g, b, int(D[r, j]), orc.arc_cost_int(c[r, j], 3, a, b)))
+        for i in pick:
+            a = int(offs[t] + i)
+            lo, hi = row_ptr[a], row_ptr[a + 1]
+            got = list(zip(gap[lo:hi].tolist(), col[lo:hi].tolist(), length[lo:hi].tolist(), cost[lo:hi].tolist()))
+            assert got == sorted(want[int(i)]), f'arc row of detection {i} of frame {t}'
+            n_arcs += len(got)
+    return n_arcs
+
+
+def _size_independent_properties(ad, P, stride):
+    cnt, conf, x, y = ad._host_dets()
+    for t in range(0, len(cnt), stride):
+        n = int(cnt[t])
+        assert np.all(np.diff(conf[t, :n].astype(np.float64)) <= 0) and conf[t, :n].min() >= np.float32(0.55)
+        d2 = (x[t, :n, None] - x[t, None, :n]).astype(np.int64) ** 2 + (y[t, :n, None] - y[t, None, :n]).astype(np.int64) ** 2
+        np.fill_diagonal(d2, 10 ** 9)
+        assert d2.min() >= 529
+    track, offs = ad._track_flat, ad._offs
+    frame_of = np.searchsorted(offs, np.arange(len(track)), side='right') - 1
+    used = track >= 0
+    order = np.lexsort((frame_of[used], track[used]))
+    tr, fr = track[used][order], frame_of[used][order]
+    same = tr[1:] == tr[:-1]
+    gaps = (fr[1:] - fr[:-1])[same]
+    assert np.all((gaps == 1) | (gaps == 2))                                       # increasing frames, at most one miss
+    assert len(np.unique(tr)) == ad.n_ids and P['MCF_MIN_FLOW'] <= ad.n_ids <= P['MCF_MAX_FLOW']
+    return int(used.sum())
+
+
+def _cost_of_trajectories(ad, arcs):
+    """Total cost of the product's trajectories recomputed from the arc list and the node costs: must equal the solver's."""
+    from axtrack_amd.detections import _arc_cost_int_vec
+    row_ptr, col, length, gap, cost = arcs
+    cnt, conf, x, y = ad._host_dets()
+    n = int(cnt.sum())
+    flat = np.concatenate([conf[t, :cnt[t]] for t in range(len(cnt))]).astype(np.float64)
+    obs = orc.observation_cost(orc.cap_conf(flat, ad.P['MCF_CONF_CAPPING_METHOD']), ad.P['MCF_MAX_CONF_COST'])
+    k = np.arange(n)
+    ee = float(ad.P['MCF_ENTRY_EXIT_COST'])
+    obs_i, en_i, ex_i = _arc_cost_int_vec(obs, 2, k, 0), _arc_cost_int_vec(np.full(n, ee), 0, k, 0), _arc_cost_int_vec(np.full(n, ee), 1, k, 0)
+    track = ad._track_flat
+    used = np.nonzero(track >= 0)[0]
+    order = used[np.argsort(track[used], kind='stable')]                            # by track, then by time (flat order)
+    tr = track[order]
+    total = int(obs_i[order].sum())
+    first = np.concatenate([[True], tr[1:] != tr[:-1]])
+    last = np.concatenate([tr[1:] != tr[:-1], [True]])
+    total += int(en_i[order[first]].sum()) + int(ex_i[order[last]].sum())
+    a, b = order[:-1][~last[:-1]], order[1:][~last[:-1]]
+    for u, v in zip(a, b):
+        lo, hi = row_ptr[u], row_ptr[u + 1]
+        j = np.nonzero(col[lo:hi] == v)[0]
+        assert len(j) == 1, 'a link of a trajectory is not an admissible arc'
+        total += int(cost[lo + j[0]])
+    return total
+
+
+@pytest.mark.parametrize('cfg', ['c4', 'c5'])
+def test_baseline_configs_4_and_5_at_full_size(weights, cfg):
+    """BASELINE config 4 (synthetic 1024x1024x1024, global min-cost flow) and config 5 (1024x1024x512 under the corridor
+    mask, path costs on the masked grid) at their STATED sizes on one GPU (the 8-GPU frame-sharded runs are the
+    driver's; the sharding itself is covered by the two-rank tests): size-independent properties of every stage over
+    the whole timelapse, and against the oracle
+      * the CNN of 16 frames sampled across the launches (64 tile-forwards) within the stated tolerance,
+      * the detection lists of those frames bit-exact given the grids,
+      * the arc rows (path lengths, admission, integer costs, global numbering) of sampled frame pairs -- every source
+        detection of 4 frames on the open grid, 6 source detections of each of 4 frames on the masked grid (the oracle's
+        masked search takes ~1 s per source),
+      * the solver's total cost recomputed from the product's trajectories, arcs and node costs."""
+    import axtrack_amd
+    T_all = {'c4': 1024, 'c5': 512}[cfg]
+    frames = synth.synth_frames(T_all, 1024, 1024, seed=0)
+    mask = synth.corridor_mask(1024, 1024, width=40, pitch=128) if cfg == 'c5' else None
+    if mask is not None:
+        frames *= mask[None].astype(np.float32)
+    P = params.load_parameters()
+    model = axtrack_amd.Detector(weights, max_batch=1024)
+    tl = axtrack_amd.Timelapse(frames, name=cfg, mask=mask)
+    ad = axtrack_amd.inference(tl, model, None, P, None, None, None)
+    F = T_all - 4
+    cnt, conf, x, y = ad._host_dets()
+    assert len(ad) == F == len(cnt) and len(ad.tile_yx) == 4 and cnt.min() > 0
+    used = _size_independent_properties(ad, P, stride=23)
+    assert used > 100 * F and ad.IDed_dets_all.shape == (ad.n_ids, 3 * F)
+    # the CNN and the detection lists of 16 frames spread over every launch of the front layers
+    sample = sorted({0, 1, 31, 32, 33, F // 5, F // 4, F // 3, F // 2 - 1, F // 2, (2 * F) // 3, (3 * F) // 4, F - 34, F - 33, F - 2, F - 1})
+    assert len(sample) == 16
+    yolo = ad._yolo[sample].cpu().numpy()
+    for k, t in enumerate(sample):
+        ref = orc.cnn_forward(weights, orc.frame_tile_stack(frames, t, ad.tile_yx))
+        np.testing.assert_allclose(yolo[k], ref, atol=CNN_ATOL, rtol=CNN_RTOL)
+    for t, (rc, rx, ry) in zip(sample, orc.detect_from_yolo(list(yolo), ad.tile_yx)):
+        n = len(rc)
+        assert cnt[t] == n and np.array_equal(conf[t, :n], rc) and np.array_equal(x[t, :n], rx) and np.array_equal(y[t, :n], ry)
+    # arcs of sampled frame pairs, and the cost of the solution
+    arcs = _product_arcs(ad)
+    n = _check_arc_rows_against_oracle(ad, arcs, [0, F // 3, F // 2, F - 3], None if cfg == 'c4' else 6, mask, 1024, 1024)
+    assert n > (5000 if cfg == 'c4' else 100)
+    assert _cost_of_trajectories(ad, arcs) == ad.mcf_total_cost
+
+
+def test_example_timelapse_substitute_against_the_oracle(tmp_path):
+    """BASELINE config 1 is examples/example_timelapse.tif through axtrack.inference() -- an external download that is not
+    in the reference tree. Its substitute: a synthetic raw uint16 timelapse of 512x512x20
+    input frames through the three API calls of examples/test.py with MCF_MAX_FLOW = 140 (test.py:19), END TO END against
+    the oracle: preprocessing within 2 ulp of f32 log2, the CNN of all 16 detection frames within tolerance, detections
+    bit-exact, the flow tracker's trajectories, total cost and IDed_dets_all equal."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('example_test', os.path.join(os.path.dirname(__file__), '..', 'examples', 'test.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ad = mod.main(T=20, dest_dir=str(tmp_path))
+    assert ad.P['MCF_MAX_FLOW'] == 140 and len(ad) == 16
+    sd = synth.synth_state_dict(42)
+    # the raw input of the example, preprocessed by the oracle
+    scale = params.DEPLOYED_STND_SCALER[1][0]
+    f0 = synth.synth_frames(20, 512, 512, seed=7)
+    raw = np.clip((2.0 ** (f0 * scale) - 1.0) * 65535.0 + 121.0 * (f0 > 0), 0, 65535).astype(np.uint16)
+    ref_frames = orc.preprocess(raw, None, offset=121 / 2 ** 16, clip_lower=55 / 2 ** 16, log_correct=True, scale=scale)
+    frames = ad.dataset.frames.cpu().numpy()
+    assert frames.shape == ref_frames.shape == (20, 512, 512)
+    assert np.array_equal(frames == 0, ref_frames == 0)
+    np.testing.assert_array_max_ulp(frames, ref_frames, maxulp=2)
+    yolo = ad._yolo.cpu().numpy()
+    for t in range(16):
+        np.testing.assert_allclose(yolo[t], orc.cnn_forward(sd, orc.frame_tile_stack(frames, t, ad.tile_yx)), atol=CNN_ATOL, rtol=CNN_RTOL)
+    ref = orc.inference(frames, sd, P=dict(orc.DEFAULTS, MCF_MAX_FLOW=140), name='example_timelapse', yolo=list(yolo))
+    cnt, conf, x, y = ad._host_dets()
+    for t, (rc, rx, ry) in enumerate(ref['dets']):
+        n = len(rc)
+        assert cnt[t] == n and np.array_equal(conf[t, :n], rc) and np.array_equal(x[t, :n], rx) and np.array_equal(y[t, :n], ry)
+    assert tracks_from_next(np.zeros(len(ad._track_flat)), ad._track_flat, ad._offs) == ref['trajs']
+    assert ad.mcf_total_cost == ref['total_cost'] and ad.n_ids == len(ref['trajs']) >= 5
+    ids, labels, info, vals = ref['ided_all']
+    df = ad.IDed_dets_all
+    assert list(df.index) == [f'Axon_{i:0>3}' for i in ids] and df.shape == (len(ids), 48)
+    assert np.array_equal(np.nan_to_num(df.to_numpy(), nan=-1), np.nan_to_num(vals, nan=-1))
+    # the path dictionary the default astar_paths_cache='to' wrote reads back to the lengths the tracker used
+    import pickle
+    paths = pickle.load(open(tmp_path / 'axon_dets' / 'example_timelapse_astar_dets_paths.pkl', 'rb'))
+    assert paths.keys() == ref['D'].keys()
+    k = sorted(paths)[3]
+    got = np.array([[500 if p is None else p.getnnz() for p in row] for row in paths[k]])
+    assert np.array_equal(got, ref['D'][k])
+
+
+def test_bare_multi_gpu_bench_invocation_runs_two_ranks_on_this_gpu():
+    """`python bench.py --gpus 2` as the driver calls it (no launcher environment): the parent starts the two ranks itself
+    (it never touches the GPU) and passes rank 0's JSON line through. Rehearsed with gloo and both ranks on cuda:0."""
+    import json, subprocess, sys
+    root = os.path.join(os.path.dirname(__file__), '..')
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--single-device',
+                        '--frames', '36', '--steps', '2', '--warmup', '1', '--no-verify'], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    b = json.loads(lines[0])
+    assert b['n_gpus'] == 2 and b['value'] > 0 and b['tracks_identical_on_all_ranks'] is True and b['scaling'] == 'weak'
+    assert b['config']['detection_frames_per_gpu'] == 32
