@@ -23,6 +23,8 @@ SIGNATURES = {
     'axt_cnn_forward': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     'axt_cnn_forward_frames': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                        c_void_p, c_void_p]),
+    'axt_cnn_front_frames': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    'axt_cnn_back': (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     'axt_cnn_flops_per_tile': (c_double, []),
     'axt_detector_set_profiling': (c_int, [c_void_p, c_int]),
     'axt_detector_read_profile': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int]),

@@ -816,6 +816,9 @@ __device__ __forceinline__ void wino_body(const float *__restrict__ in, const fl
     unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
 #endif
+    // (Tried and dropped in round 3: the epilogue of a finished tile at the HEAD of the next chunk, so that the lighter wave's
+    // next MFMAs run beside the heavier wave's output transform -- no difference within 0.5 %: vector instructions of one
+    // wave make little headway beside the other wave's f32 MFMAs, which is also why the input transform is scalar code.)
     auto step = [&](int PAR) {
         const bool last = c + 1 == NCH;
         // U of the chunk after this one: the next chunk of this tile's group, or the first chunk of the next tile's group
@@ -2019,6 +2022,47 @@ int axt_cnn_forward_frames(axt_detector *det, const float *d_frames, int T_all, 
     }
     if (n_frames == 0) return AXT_OK;
     return forward_items(det, d_frames, H, W, t0, 1, n_frames * n_tiles, n_tiles, tl, d_yolo, (hipStream_t)stream);
+}
+
+int axt_cnn_front_frames(axt_detector *det, const float *d_frames, int T_all, int H, int W, int t0, int n_frames,
+                         const int32_t *h_tile_yx, int n_tiles, int item0, void *stream)
+{
+    AXT_REQUIRE(det && d_frames && h_tile_yx, "null argument");
+    AXT_REQUIRE(n_tiles >= 1 && n_tiles <= 256, "n_tiles %d out of range [1,256]", n_tiles);
+    AXT_REQUIRE(t0 >= 0 && n_frames >= 0 && t0 + n_frames + 4 <= T_all, "frames [%d,%d) + context exceed T_all=%d",
+                t0, t0 + n_frames, T_all);
+    const int n_items = n_frames * n_tiles;
+    AXT_REQUIRE(item0 >= 0 && item0 + n_items <= det->max_batch, "items [%d,%d) exceed the detector's max_batch %d", item0,
+                item0 + n_items, det->max_batch);
+    TileList tl;
+    tl.n = n_tiles;
+    for (int k = 0; k < n_tiles; ++k) {
+        const int ty = h_tile_yx[2 * k], tx = h_tile_yx[2 * k + 1];
+        AXT_REQUIRE(ty >= 0 && tx >= 0 && ty * AXT_TILE < H && tx * AXT_TILE < W, "tile %d (%d,%d) outside %dx%d", k,
+                    ty, tx, H, W);
+        tl.yx[2 * k] = (short)ty;
+        tl.yx[2 * k + 1] = (short)tx;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    for (int cb = 0; cb < n_items; cb += kChunkB) {
+        const int nbb = (n_items - cb < kChunkB) ? n_items - cb : kChunkB;
+        for (int c = 0; c < nbb; c += kChunkA) {
+            const int nc = (nbb - c < kChunkA) ? nbb - c : kChunkA;
+            const int rc = run_front_a(det, d_frames, H, W, t0, 1, cb + c, n_tiles, tl, nc, c, st);
+            if (rc) return rc;
+        }
+        const int rc = run_front_b(det, nbb, det->d_act[4] + (size_t)(item0 + cb) * 80 * 32 * 32, st);
+        if (rc) return rc;
+    }
+    return AXT_OK;
+}
+
+int axt_cnn_back(axt_detector *det, int n_items, float *d_yolo, void *stream)
+{
+    AXT_REQUIRE(det && d_yolo, "null argument");
+    AXT_REQUIRE(n_items >= 0 && n_items <= det->max_batch, "%d items exceed the detector's max_batch %d", n_items, det->max_batch);
+    if (n_items == 0) return AXT_OK;
+    return run_back(det, n_items, d_yolo, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -75,8 +75,11 @@ __device__ __forceinline__ void wave_argmin(long &key, int &idx)
 // NC > 0 (3 or 9): frames with at most 64*NC detection slots -- the per-column search state (dual, distance, predecessor, matched
 // row, flags) lives in NC registers per lane instead of LDS, so that one search step costs one LDS round trip (the
 // cost row and the row dual) instead of a dozen dependent ones. NC == 0: any cap, column state in LDS.
+// NC > 0: launched with 256 threads. All four waves share the initialisation (every row's cheapest option: n x m link
+// costs at ~1 000 cycles each -- the 64-bit identity hash -- were 40 % of the kernel on one wave), then waves 1-3 leave
+// and wave 0 runs the searches alone.
 template <int GAP, int NC>
-__global__ __launch_bounds__(64) void hungarian_pair_kernel(
+__global__ __launch_bounds__(NC > 0 ? 256 : 64) void hungarian_pair_kernel(
     const int *__restrict__ x, const int *__restrict__ y, const int *__restrict__ count,
     const int *__restrict__ frame_off, int n_frames, int cap, int H, int W, int max_dist, int conn8,
     int dmax, const long *__restrict__ units, long thr_units,
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(64) void hungarian_pair_kernel(
     const short *__restrict__ dtab, int tab_gaps, const long *__restrict__ ctab)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
-    const int t = t_first + blockIdx.x, tb = t + GAP, lane = threadIdx.x;
+    const int t = t_first + blockIdx.x, tb = t + GAP, lane = threadIdx.x, nthr = NC > 0 ? 256 : 64;
     if (tb >= n_frames) return;
     const int n = min(count[t], cap), m = min(count[tb], cap);
     long *v = reinterpret_cast<long *>(hsm);            // [cap] column duals
@@ -101,23 +104,26 @@ __global__ __launch_bounds__(64) void hungarian_pair_kernel(
     long *ccache = lunits + dmax + 1;                   // [cdim][cdim] cost matrix of the pair, if it fits
     unsigned char *in_sc = reinterpret_cast<unsigned char *>(ccache + (long)cdim * cdim);   // [cap]
     unsigned char *col_ok = in_sc + cap;                // [cap] column takes part
+    long *dummy = reinterpret_cast<long *>(col_ok + cap + ((8 - (2 * cap) % 8) % 8));     // [cap] cost of leaving a row unlinked
+    long *pbest = dummy + cap;                          // [4 cap] (NC > 0) the initialisation's partial minima ...
+    int *pbj = reinterpret_cast<int *>(pbest + 4 * cap);    // [4 cap] ... and their columns
     const bool cached = n <= cdim && m <= cdim;
 
     const long a0 = frame_off[t], b0 = frame_off[tb];
-    for (int j = lane; j < m; j += 64) {
+    for (int j = lane; j < m; j += nthr) {
         v[j] = 0;
         row4col[j] = -1;
         xs[j] = x[(long)tb * cap + j];
         ys[j] = y[(long)tb * cap + j];
         col_ok[j] = (GAP == 1) ? 1 : (pred1[(long)tb * cap + j] < 0);
     }
-    for (int i = lane; i < n; i += 64) {
+    for (int i = lane; i < n; i += nthr) {
         u[i] = 0;
         col4row[i] = -1;
         xr[i] = x[(long)t * cap + i];
         yr[i] = y[(long)t * cap + i];
     }
-    for (int d = lane; d <= dmax; d += 64) lunits[d] = units[d];
+    for (int d = lane; d <= dmax; d += nthr) lunits[d] = units[d];
     __syncthreads();
 
     // cost of linking row i to column j (HINF: not admitted)
@@ -138,21 +144,55 @@ __global__ __launch_bounds__(64) void hungarian_pair_kernel(
     // ---- initialisation (Jonker-Volgenant): every row gets u = its cheapest option (a column or its own dummy),
     // which keeps all reduced costs >= 0 with v = 0, and is assigned to that option if it is still free (tight
     // pair). Only rows that lose such a contest need an augmenting search. Lanes work on different rows here.
-    for (int i = lane; i < n; i += 64) {
-        const bool active = (GAP == 1) || (succ1[(long)t * cap + i] < 0);
-        long best = h_arc_cost_int(thr_units, 1, a0 + i, 0);
-        int bj = -2;
-        if (active) {
-            for (int j = 0; j < m; ++j) {
-                const long c = link_cost(i, j);
-                if (cached) ccache[i * cdim + j] = c;
-                if (c < best) { best = c; bj = j; }
+    if constexpr (NC > 0) {
+        // (row, quarter of the columns) per thread; the four partial minima of a row are combined in column order, so the
+        // result is the sequential scan's (first column among equal costs; the dummy wins a tie with a column)
+        for (int idx = lane; idx < 4 * n; idx += nthr) {
+            const int i = idx >> 2, qq = idx & 3;
+            const bool active = (GAP == 1) || (succ1[(long)t * cap + i] < 0);
+            long best = HINF;
+            int bj = -1;
+            if (active) {
+                const int j1 = (int)(((long)m * (qq + 1)) >> 2);
+                for (int j = (int)(((long)m * qq) >> 2); j < j1; ++j) {
+                    const long c = link_cost(i, j);
+                    if (cached) ccache[i * cdim + j] = c;
+                    if (c < best) { best = c; bj = j; }
+                }
             }
+            pbest[idx] = best;
+            pbj[idx] = bj;
+            if (qq == 0) dummy[i] = h_arc_cost_int(thr_units, 1, a0 + i, 0);
         }
-        u[i] = best;
-        pred[i] = bj;                    // pred[] is free until the first search: holds the row's preferred column
+        __syncthreads();
+        for (int i = lane; i < n; i += nthr) {
+            long best = dummy[i];
+            int bj = -2;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+                if (pbest[4 * i + qq] < best) { best = pbest[4 * i + qq]; bj = pbj[4 * i + qq]; }
+            u[i] = best;
+            pred[i] = bj;                // pred[] is free until the first search: holds the row's preferred column
+        }
+        __syncthreads();
+        if (lane >= 64) return;          // the searches are one wave's work (a barrier no longer counts a wave that has ended)
+    } else {
+        for (int i = lane; i < n; i += 64) {
+            const bool active = (GAP == 1) || (succ1[(long)t * cap + i] < 0);
+            long best = dummy[i] = h_arc_cost_int(thr_units, 1, a0 + i, 0);
+            int bj = -2;
+            if (active) {
+                for (int j = 0; j < m; ++j) {
+                    const long c = link_cost(i, j);
+                    if (cached) ccache[i * cdim + j] = c;
+                    if (c < best) { best = c; bj = j; }
+                }
+            }
+            u[i] = best;
+            pred[i] = bj;                // pred[] is free until the first search: holds the row's preferred column
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (lane == 0) {
         for (int i = 0; i < n; ++i) {
             if (GAP == 2 && succ1[(long)t * cap + i] >= 0) continue;
@@ -187,7 +227,7 @@ __global__ __launch_bounds__(64) void hungarian_pair_kernel(
                 if (lane == 0) sr[n_sr] = cur;
                 ++n_sr;
                 const long ucur = u[cur];
-                const long rd = minVal + h_arc_cost_int(thr_units, 1, a0 + cur, 0) - ucur;
+                const long rd = minVal + dummy[cur] - ucur;
                 if (rd < best_dummy) { best_dummy = rd; dummy_row = cur; }
                 long bkey = HINF;
                 int bidx = 0x7fffffff;
@@ -271,7 +311,7 @@ __global__ __launch_bounds__(64) void hungarian_pair_kernel(
                 if (lane == 0) sr[n_sr] = cur;
                 ++n_sr;
                 const long ucur = u[cur];
-                const long rd = minVal + h_arc_cost_int(thr_units, 1, a0 + cur, 0) - ucur;
+                const long rd = minVal + dummy[cur] - ucur;
                 if (rd < best_dummy) { best_dummy = rd; dummy_row = cur; }
                 long bkey = HINF;
                 int bidx = 0x7fffffff;
@@ -482,7 +522,8 @@ static int hungarian_pairs_impl(const int32_t *d_x, const int32_t *d_y, const in
     AXT_LAUNCH_CHECK();
     int rc = axt_frame_offsets(d_count, n_frames, cap, frame_off, st);
     if (rc) return rc;
-    const size_t lds_base = (size_t)cap * (3 * 8 + 8 * 4 + 2) + 8 + (size_t)(max_dist + 2) * 8;
+    const size_t lds_base = (size_t)cap * (3 * 8 + 8 * 4 + 2) + 8 + (size_t)(max_dist + 2) * 8 + 8 +
+                            (size_t)cap * 8 + (cap <= 576 ? (size_t)cap * 48 : 0);       // + dummy costs, + the initialisation's partial minima
     AXT_REQUIRE(lds_base <= 160 * 1024, "axt_hungarian_pairs: cap %d needs %zu bytes of LDS", cap, lds_base);
     // pairs with at most cdim x cdim detections keep their cost matrix in LDS (72 KiB) instead of recomputing it
     int cdim = cap < 96 ? cap : 96;
@@ -515,7 +556,7 @@ static int hungarian_pairs_impl(const int32_t *d_x, const int32_t *d_y, const in
         if (rc) return rc;
     }
     if (e1 > t_begin) {
-        hipLaunchKernelGGL((cap <= 192 ? hungarian_pair_kernel<1, 3> : cap <= 576 ? hungarian_pair_kernel<1, 9> : hungarian_pair_kernel<1, 0>), dim3(e1 - t_begin), dim3(64), lds, st, d_x, d_y, d_count, frame_off,
+        hipLaunchKernelGGL((cap <= 192 ? hungarian_pair_kernel<1, 3> : cap <= 576 ? hungarian_pair_kernel<1, 9> : hungarian_pair_kernel<1, 0>), dim3(e1 - t_begin), dim3(cap <= 576 ? 256 : 64), lds, st, d_x, d_y, d_count, frame_off,
                            n_frames, cap, H, W, max_dist, conn8, h_dmax[0], (const long *)d_cost_units, (long)thr_units,
                            (const int *)nullptr, (const int *)nullptr, succ1, pred1, cdim, t_begin, (const short *)dtab, max_gap,
                            (const long *)d_ctab);
@@ -523,7 +564,7 @@ static int hungarian_pairs_impl(const int32_t *d_x, const int32_t *d_y, const in
     }
     const int e2 = t_end < n_frames - 2 ? t_end : n_frames - 2;
     if (max_gap == 2 && e2 > t_begin) {
-        hipLaunchKernelGGL((cap <= 192 ? hungarian_pair_kernel<2, 3> : cap <= 576 ? hungarian_pair_kernel<2, 9> : hungarian_pair_kernel<2, 0>), dim3(e2 - t_begin), dim3(64), lds, st, d_x, d_y, d_count, frame_off,
+        hipLaunchKernelGGL((cap <= 192 ? hungarian_pair_kernel<2, 3> : cap <= 576 ? hungarian_pair_kernel<2, 9> : hungarian_pair_kernel<2, 0>), dim3(e2 - t_begin), dim3(cap <= 576 ? 256 : 64), lds, st, d_x, d_y, d_count, frame_off,
                            n_frames, cap, H, W, max_dist, conn8, h_dmax[1],
                            (const long *)d_cost_units + (max_dist + 1), (long)thr_units, (const int *)succ1,
                            (const int *)pred1, succ2, pred2, cdim, t_begin, (const short *)dtab, max_gap, (const long *)d_ctab);

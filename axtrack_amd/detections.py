@@ -98,11 +98,12 @@ class AxonDetections(object):
             self._set_detections_from_tables(self.from_cache('_detections'))
             return
         frames = self.dataset.frames
+        if hasattr(self.model, 'set_arith'):
+            self.model.set_arith(self.P.get('CNN_ARITH', 'f32'))       # read at inference time, like every parameter
+        streamed = self._detect_streaming() if getattr(self.dataset, '_pending', False) else None
         self.tile_yx = self.dataset.tile_yx
         if not self.tile_yx:
             raise ValueError('the timelapse is empty (no tile has a non-zero pixel)')
-        if hasattr(self.model, 'set_arith'):
-            self.model.set_arith(self.P.get('CNN_ARITH', 'f32'))       # read at inference time, like every parameter
         # the frames of timepoint_subset (AxonDetections.py:111), one launch sequence per run of consecutive frames
         sub = self.timepoint_subset
         runs, a = [], 0
@@ -110,8 +111,11 @@ class AxonDetections(object):
             if k == len(sub) or sub[k] != sub[k - 1] + 1:
                 runs.append((sub[a], k - a))
                 a = k
-        parts = [self.model.detect_frames(frames, self.tile_yx, t0, n) for t0, n in runs]
-        self._yolo = parts[0] if len(parts) == 1 else torch.cat(parts, 0)
+        if streamed is not None and streamed[0] == self.tile_yx and sub == list(range(self.dataset.sizet)):
+            self._yolo = streamed[1]                                 # computed chunk by chunk beside the copies
+        else:
+            parts = [self.model.detect_frames(frames, self.tile_yx, t0, n) for t0, n in runs]
+            self._yolo = parts[0] if len(parts) == 1 else torch.cat(parts, 0)
         self._tiled_tables = None
         thr = float(np.float32(self.all_conf_thrs.min()))
         self.d_conf, self.d_x, self.d_y, self.d_count = hp.decode_stitch_nms(
@@ -126,6 +130,33 @@ class AxonDetections(object):
         self._host = None
         if cache == 'to':
             self.to_cache('_detections', self._detections)
+
+    def _detect_streaming(self):
+        """Host-resident input (Timelapse.from_host_u16): the CNN of the detection frames every chunk completes is
+        enqueued right behind the chunk's preprocessing, while the next chunk's H2D copy runs on the copy stream. The
+        kept-tile list is a property of the whole timelapse (Timelapse.py:551-558) and only known after the last chunk:
+        the chunks are detected with every tile, which is the final list unless some tile is empty at EVERY time point
+        (then detect_dataset repeats the detection on the resident frames with the right list). Returns (tile list used,
+        YOLO grids [sizet, n_tiles, 12,12,3])."""
+        ds = self.dataset
+        tiles = [(ty, tx) for ty in range(ds.ytiles) for tx in range(ds.xtiles)]
+        ctx = ds.temporal_context
+        # the front of the network (conv blocks 0-5: 87 % of the FLOPs) chunk by chunk, the rest once for all frames: the first
+        # linear layer streams its 168 MB of weights per call, whatever the batch
+        split = ds.sizet * len(tiles) <= getattr(self.model, 'max_batch', 0)
+        parts, done, occ = [], 0, None
+        for a, b, occ in ds.stream_chunks():
+            ready = min(max(b - 2 * ctx, 0), ds.sizet)               # detection frame t reads input frames t .. t + 2 ctx
+            if ready > done:
+                if split:
+                    self.model.front_frames(ds.frames, tiles, done, ready - done, done * len(tiles))
+                else:
+                    parts.append(self.model.detect_frames(ds.frames, tiles, done, ready - done))
+                done = ready
+        yolo = self.model.back(ds.sizet, len(tiles)) if split else (parts[0] if len(parts) == 1 else torch.cat(parts, 0))
+        ds._occ_done.synchronize()                                    # (a few bytes, behind the last chunk's preprocessing)
+        ds._tile_yx = hp.tile_list(ds._occ_host, ds.sizey, ds.sizex)
+        return tiles, yolo
 
     def _shrink_capacity(self, fullest):
         cap = min(-(-max(int(fullest), 1) // 64) * 64, int(self.d_conf.shape[1]))
@@ -162,6 +193,19 @@ class AxonDetections(object):
         if dist.is_initialized() and dist.get_world_size(group) > 1:
             r = dist.get_rank(group)
             self._shard = (r * local, (r + 1) * local, group)       # this rank's frames within the gathered arrays
+
+    def set_detections(self, conf, x, y, count):
+        """Adopt detection lists that are already arrays (conf f32 [F,cap], x / y i32 [F,cap], count i32 [F], every frame
+        in descending confidence): association-only workloads (bench.py --workload assoc-*) and detections produced
+        elsewhere. The arrays go to the dataset's device; detect_dataset() is not needed afterwards."""
+        dev = self.device
+        as_dev = lambda a, dt: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))).to(device=dev, dtype=dt).contiguous()
+        self.d_conf, self.d_x, self.d_y, self.d_count = (as_dev(conf, torch.float32), as_dev(x, torch.int32), as_dev(y, torch.int32),
+                                                         as_dev(count, torch.int32))
+        if self.d_conf.dim() != 2 or self.d_x.shape != self.d_conf.shape or self.d_y.shape != self.d_conf.shape \
+                or self.d_count.shape != (self.d_conf.shape[0],):
+            raise ValueError('conf, x, y must be [F, cap] and count [F]')
+        self._host, self._det_tables, self._yolo, self._tiled_tables = None, None, None, None
 
     def _host_dets(self):
         """(count i32 [F], conf f32 [F,cap], x, y) on the host, fetched once."""

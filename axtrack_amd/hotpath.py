@@ -147,12 +147,33 @@ class Detector:
         return out
 
 
-def preprocess_u16(raw, mask=None, offset=0.0, clip_lower=0.0, log_correct=True, scale=1.0):
+    def front_frames(self, frames, tile_yx, t0, n_frames, item0):
+        """Conv blocks 0-5 of detection frames t0 .. t0+n_frames-1 into the detector's batch buffer from item `item0`
+        (axt_cnn_front_frames): input that arrives in chunks. back() finishes the pass for all items at once."""
+        T_all, H, W = frames.shape
+        tile_yx = np.ascontiguousarray(tile_yx, np.int32).reshape(-1, 2)
+        assert frames.is_contiguous() and frames.dtype == torch.float32 and frames.device == self.device
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.axt_cnn_front_frames(self._h, frames.data_ptr(), T_all, H, W, t0, n_frames, tile_yx.ctypes.data,
+                                                      len(tile_yx), int(item0), _stream()), 'axt_cnn_front_frames')
+
+    def back(self, n_frames, n_tiles):
+        """The rest of the forward pass for items 0 .. n_frames*n_tiles-1 of the batch buffer -> [n_frames, n_tiles, 12,12,3]."""
+        out = torch.empty((n_frames, n_tiles, S, S, 3), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.axt_cnn_back(self._h, n_frames * n_tiles, out.data_ptr(), _stream()), 'axt_cnn_back')
+        return out
+
+
+def preprocess_u16(raw, mask=None, offset=0.0, clip_lower=0.0, log_correct=True, scale=1.0, out=None):
     """Fused dense preprocessing (Timelapse.py:205-326) of a raw uint16 timelapse that already sits on the GPU.
-    raw: torch.uint16 (or int16-viewed) [T,H,W]; mask: uint8/bool [H,W] on the same device or None."""
+    raw: torch.uint16 (or int16-viewed) [T,H,W]; mask: uint8/bool [H,W] on the same device or None; out: optional
+    contiguous f32 [T,H,W] to write into (a slice of the timelapse's frame buffer when the input arrives in chunks)."""
     T, H, W = raw.shape
     assert raw.is_contiguous() and raw.element_size() == 2
-    out = torch.empty((T, H, W), dtype=torch.float32, device=raw.device)
+    if out is None:
+        out = torch.empty((T, H, W), dtype=torch.float32, device=raw.device)
+    assert out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (T, H, W) and out.device == raw.device
     if mask is not None:
         mask = mask.to(device=raw.device, dtype=torch.uint8).contiguous()
     lib = _lib.load()

@@ -156,7 +156,7 @@ def synth_detections(n_frames, H, W, n_alive=75, seed=0, mean_life=120, p_detect
     random-init benchmark weights give a static scene. About `n_alive` cones are alive in every frame; a cone lives
     ~mean_life frames (geometric), moves by a momentum random walk (reflecting at the borders), is missed with
     probability 1 - p_detect, is reported with +-jitter px of localisation noise and a confidence around its own level
-    in [0.62, 1.05] (+-0.05; below the 0.55 floor = missed); `clutter` x n_alive false detections per frame with
+    in [0.7, 1.1] (+-0.05; below the 0.55 floor = missed); `clutter` x n_alive false detections per frame with
     confidence in [0.55, 0.7). Every frame then goes through the detector's own greedy NMS rule (descending confidence,
     dx^2+dy^2 < min_dist^2 suppressed; AxonDetections.py:250-278) and is ordered by descending confidence.
 
@@ -170,7 +170,7 @@ def synth_detections(n_frames, H, W, n_alive=75, seed=0, mean_life=120, p_detect
     n_cones = int(births.sum())
     t_birth = np.repeat(np.arange(F), births)
     life = np.ceil(-np.log(1.0 - uniform01(s + 2, (n_cones,))) * mean_life).astype(np.int64).clip(1)
-    level = 0.62 + 0.43 * uniform01(s + 3, (n_cones,))
+    level = 0.7 + 0.4 * uniform01(s + 3, (n_cones,))
     pos0 = uniform01(s + 4, (n_cones, 2)) * np.array([W - 1.0, H - 1.0])
     vel0 = (uniform01(s + 5, (n_cones, 2)) * 2 - 1) * max_step * 0.5
     cap = int(cap or max(64, -(-int(n_alive * (1.6 + clutter)) // 64) * 64))

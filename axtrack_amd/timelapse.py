@@ -106,6 +106,87 @@ class Timelapse:
                    tilesize=d.get('tilesize', 512), device=device, pixelsize=d.get('pixelsize'), dt=d.get('dt'),
                    incubation_time=d.get('incubation_time'))
 
+    # ------------------------------------------------------------------ host-resident input (Timelapse.py:205-326 + 492-566)
+    @classmethod
+    def from_host_u16(cls, raw, name='timelapse', mask=None, offset=121, clip=55, log_correct=True, scale=0.015176106,
+                      chunk_frames=96, device='cuda:0', **kw):
+        """A timelapse whose raw uint16 frames [T_all,H,W] still sit in HOST memory (pinned here if they are not), as the
+        reference's inference() starts from (its Timelapse is a host object; construct_tiles copies to the device,
+        Timelapse.py:492-566). Nothing is copied yet: AxonDetections.detect_dataset() streams the frames in chunks of
+        `chunk_frames` -- H2D copies on a second stream into two staging buffers, the fused preprocessing pass
+        (axt_preprocess_u16) into this object's frame buffer and the CNN of the detection frames a chunk completes, so the
+        copy of chunk k + 1 runs beside the kernels of chunk k. Afterwards the object is an ordinary resident Timelapse.
+        mask: [H,W] or None (a mask per frame needs the resident path: prepare_input_data)."""
+        a = raw if isinstance(raw, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(raw)).view(np.int16))
+        if a.dtype == torch.uint16:
+            a = a.view(torch.int16)
+        if a.dtype != torch.int16 or a.dim() != 3:
+            raise TypeError('raw timelapses are uint16 [T_all,H,W]')
+        if mask is not None and np.asarray(mask).ndim != 2:
+            raise ValueError('from_host_u16 takes a static [H,W] mask; a mask per frame goes through prepare_input_data')
+        self = cls.__new__(cls)
+        T, H, W = a.shape
+        dev = torch.device(device)
+        frames = torch.empty((T, H, W), dtype=torch.float32, device=dev)
+        cls.__init__(self, frames, name=name, mask=mask, device=device, **kw)
+        self.frames = frames                                            # (the constructor keeps the same storage)
+        self._host_raw = a if a.is_pinned() else a.pin_memory()
+        off = 0.0 if not offset else (offset / 2 ** 16 if isinstance(offset, int) else float(offset))
+        lo = 0.0 if not clip else (clip / 2 ** 16 if isinstance(clip, int) else float(clip))
+        m = None if mask is None else torch.from_numpy(np.ascontiguousarray(np.asarray(mask).astype(np.uint8))).to(dev)
+        self._pre = (m, off, lo, bool(log_correct), float(scale))
+        self._chunk = max(int(chunk_frames), 2 * self.temporal_context + 1)
+        self._pending = True
+        return self
+
+    def stream_chunks(self):
+        """Generator over the chunks of a host-resident timelapse. All H2D copies are enqueued at once on a copy stream, in
+        pieces of 16 frames into a device buffer for the raw timelapse (2 bytes per pixel; no staging buffer to recycle), each
+        followed by an event. The compute (current) stream then takes the frames in chunks that GROW -- 16, 32, 48, 64 frames,
+        then `chunk_frames` -- so that the first kernels start after ~0.17 ms of copying while later chunks are large enough
+        for full launches (PCIe delivers a 512x512 frame in 10.6 us, the detector needs ~14 us for it: the copies stay ahead
+        of a schedule that grows no faster than that ratio allows; profiles/r03j_trace). Per chunk: wait for its last piece, the fused preprocessing pass into the frame buffer, the
+        tile occupancy; then yields (first frame, one past last frame, occupancy bytes so far) so that the caller can
+        enqueue the work the chunk completes. Leaves the frames resident."""
+        from . import hotpath as hp
+        dev = self.frames.device
+        T, H, W = self.frames.shape
+        piece = 16
+        copy_stream = torch.cuda.Stream(device=dev)
+        compute = torch.cuda.current_stream(dev)
+        d_raw = torch.empty((T, H, W), dtype=torch.int16, device=dev)
+        landed = []
+        with torch.cuda.stream(copy_stream):
+            for a in range(0, T, piece):
+                d_raw[a:a + piece].copy_(self._host_raw[a:a + piece], non_blocking=True)
+                landed.append(copy_stream.record_event())
+        m, off, lo, logc, scale = self._pre
+        a, k = 0, 0
+        while a < T:
+            n = min((16, 32, 48, 64)[k], self._chunk) if k < 4 else self._chunk
+            b = min(a + n, T)
+            if T - b < piece:
+                b = T
+            compute.wait_event(landed[(b - 1) // piece])
+            hp.preprocess_u16(d_raw[a:b], m, off, lo, logc, scale, out=self.frames[a:b])
+            occ = None
+            if b == T:
+                # the kept-tile list (one pass over the finished frames) goes to the host on the copy stream, behind this
+                # point of the compute stream only: the host does not wait for the CNN launches the caller enqueues for
+                # this last chunk
+                occ = hp.tile_occupancy_bytes(self.frames)
+                ready = compute.record_event()
+                self._occ_host = _pinned_bytes(int(occ.numel()))
+                with torch.cuda.stream(copy_stream):
+                    copy_stream.wait_event(ready)
+                    self._occ_host.copy_(occ, non_blocking=True)
+                    self._occ_done = copy_stream.record_event()
+            yield a, b, occ
+            a, k = b, k + 1
+        d_raw.record_stream(copy_stream)
+        self._pending = False
+        self._host_raw = None
+
     @property
     def tile_yx(self):
         """Row-major list of the (tile_row, tile_col) that hold a non-zero pixel at some time point: the reference's
@@ -137,6 +218,16 @@ class Timelapse:
     @property
     def device(self):
         return self.frames.device
+
+
+_PINNED = {}
+
+
+def _pinned_bytes(n):
+    """A pinned host byte buffer of n bytes, allocated once per size (pinning costs ~100 us, more than the copy it serves)."""
+    if n not in _PINNED:
+        _PINNED[n] = torch.empty((n,), dtype=torch.uint8, pin_memory=True)
+    return _PINNED[n]
 
 
 def preprocess(imseq, mask=None, offset=121, clip=55, log_correct=True, scale=0.015176106, device='cuda:0', pad=None):

@@ -42,7 +42,10 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--workload', default='c3', choices=['c2', 'c3'])
+    ap.add_argument('--workload', default='c3', choices=['c2', 'c3', 'assoc-c3', 'assoc-c4'],
+                    help="c3 (default, BASELINE config 3) / c2 (detection only); assoc-c3 / assoc-c4: ASSOCIATION ONLY on the detections of a "
+                         "scene of moving growth cones (births, deaths, misses, clutter; synth.synth_detections) at the size of config 3 / 4 -- "
+                         "separate lines for the flow tracker, whose cost depends on the scene (the random-init detector gives a static one)")
     ap.add_argument('--assoc', default='hungarian', choices=['hungarian', 'mcf'],
                     help="association of workload c3: 'hungarian' = BASELINE config 3 as written (frame-to-frame), "
                          "'mcf' = the reference's global min-cost-flow tracker")
@@ -51,6 +54,12 @@ def main():
                          "F(2x2,3x3) on the f32 matrix pipe, every operation f32), 'f32_direct' (direct convolution on the f32 "
                          "matrix pipe) or the opt-in 'bf16x3' (three bf16 terms per operand on the bf16 matrix pipe, f32 "
                          "accumulation): SEPARATE lines")
+    ap.add_argument('--input', default='hbm', choices=['hbm', 'host'],
+                    help="'hbm' (the headline): preprocessed f32 frames resident in HBM when the timed region starts; 'host': raw "
+                         "uint16 frames in pinned host memory -- every pass copies them in chunks on a second stream beside the "
+                         "preprocessing and the CNN of the previous chunk (a SEPARATE line: the PCIe-inclusive rate)")
+    ap.add_argument('--no-host-variant', action='store_true', help='skip the host-resident-input passes after the timed region')
+    ap.add_argument('--chunk', type=int, default=96, help='largest chunk of input frames of --input host (the chunks grow from 16)')
     ap.add_argument('--frames', type=int, default=256, help='input frames per GPU (T_all)')
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--cpu-frames', type=int, default=252, help='detection frames of the CPU-baseline sample (0 = skip)')
@@ -69,6 +78,8 @@ def main():
         raise SystemExit(launch_ranks(args.gpus))
     global torch
     import torch
+    if args.workload.startswith('assoc'):
+        return assoc_only(args)
 
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -117,13 +128,29 @@ def main():
     wino_blocks = ('conv2', 'conv4', 'conv5', 'conv7', 'conv8', 'conv10')  # the stride-1 blocks (Winograd in the default arithmetic)
     n_tiles = (-(-H // 512)) * (-(-W // 512))
     model = axtrack_amd.Detector(sd, max_batch=min(per_rank * n_tiles, 1024), device=dev)
-    tl = axtrack_amd.Timelapse(frames, name='bench', device=dev)
+    raw_pinned = None
+    if args.input == 'host':
+        if world > 1:
+            raise SystemExit('--input host is a one-GPU line')
+        # the raw 16-bit timelapse whose preprocessing gives (nearly) these frames: offset 121, clip 55, log2, train-set std
+        scale = params.DEPLOYED_STND_SCALER[1][0]
+        raw = np.clip((2.0 ** (frames.astype(np.float64) * scale) - 1.0) * 65535.0 + 121.0 * (frames > 0), 0, 65535).astype(np.uint16)
+        raw_pinned = torch.from_numpy(raw.view(np.int16)).pin_memory()
+        host_tl = lambda: axtrack_amd.Timelapse.from_host_u16(raw_pinned, name='bench', offset=121, clip=55, scale=scale,
+                                                             chunk_frames=args.chunk, device=dev)
+        tl = host_tl()
+        for _ in tl.stream_chunks():
+            pass
+        if frames_host is not None:
+            frames_host = tl.frames.cpu().numpy()          # the checker reads what the preprocessing produced
+    else:
+        tl = axtrack_amd.Timelapse(frames, name='bench', device=dev)
     del frames
     if world > 1:
         tl.sync_tile_occupancy()          # the kept-tile list is a property of the whole timelapse (Timelapse.py:551-558)
 
     def step():
-        ad = axtrack_amd.AxonDetections(model, tl, P, None)
+        ad = axtrack_amd.AxonDetections(model, host_tl() if raw_pinned is not None else tl, P, None)
         ad.detect_dataset(cache=None)
         if args.workload == 'c3':
             if world > 1:
@@ -177,7 +204,7 @@ def main():
         stages[name] = round((time.perf_counter() - t) * 1e3, 3)
         return r
     from axtrack_amd import sharded
-    ad2 = axtrack_amd.AxonDetections(model, tl, P, None)
+    ad2 = axtrack_amd.AxonDetections(model, host_tl() if raw_pinned is not None else tl, P, None)
     timed('detect_ms', lambda: ad2.detect_dataset(cache=None))
     if args.workload == 'c3':
         sharded.COLLECTIVE_MS = {}                     # per-collective wall time of this (untimed, synchronised) step
@@ -219,6 +246,35 @@ def main():
                   'ms_per_step': round(dtd * 1e3, 3), 'steps': 3}
         model.set_arith(args.arith)
 
+    # the same pass from host-resident raw input, measured in the same run (after the timed region): the PCIe-inclusive rate
+    host_variant = None
+    if args.input == 'hbm' and world == 1 and not args.no_host_variant:
+        scale = params.DEPLOYED_STND_SCALER[1][0]
+        fr = tl.frames.cpu().numpy()
+        raw = np.clip((2.0 ** (fr.astype(np.float64) * scale) - 1.0) * 65535.0 + 121.0 * (fr > 0), 0, 65535).astype(np.uint16)
+        del fr
+        rp = torch.from_numpy(raw.view(np.int16)).pin_memory()
+        def step_host():
+            t_ = axtrack_amd.Timelapse.from_host_u16(rp, name='bench', offset=121, clip=55, scale=scale, chunk_frames=args.chunk, device=dev)
+            a = axtrack_amd.AxonDetections(model, t_, P, None)
+            a.detect_dataset(cache=None)
+            if args.workload == 'c3':
+                a.assign_ids(None, None)
+            return a
+        step_host()
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        for _ in range(5):
+            ah = step_host()
+        torch.cuda.synchronize(dev)
+        dth = (time.perf_counter() - t) / 5
+        host_variant = {'input': 'host_u16', 'value': round(total_frames / dth, 2), 'unit': 'frames/s', 'ms_per_step': round(dth * 1e3, 3),
+                        'steps': 5, 'chunk_frames': args.chunk, 'h2d_bytes_per_step': int(rp.numel() * 2),
+                        'detections': int(ah._host_dets()[0].sum()),
+                        'what': 'raw uint16 frames in pinned host memory, copied in chunks on a second stream beside axt_preprocess_u16 '
+                                'and the CNN of the previous chunk; python bench.py --input host prints it as a line of its own'}
+        del rp, raw
+
     # the other association variant, measured in the same run (untimed region, one step) for transparency
     other = None
     if args.workload == 'c3' and world == 1:
@@ -236,8 +292,9 @@ def main():
     if rank == 0:
         value = total_frames * args.steps / dt
         out = {
-            'metric': 'frames/sec end-to-end detect+associate, 512x512xT timelapse' if args.workload == 'c3'
-                      else 'frames/sec detection only (CNN forward + NMS), 512x512xT timelapse',
+            'metric': ('frames/sec end-to-end detect+associate, 512x512xT timelapse' if args.workload == 'c3'
+                       else 'frames/sec detection only (CNN forward + NMS), 512x512xT timelapse')
+                      + (' -- raw uint16 input in host memory, H2D copy and preprocessing inside every pass (PCIe-inclusive)' if args.input == 'host' else ''),
             'value': round(value, 2), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None,
@@ -249,6 +306,10 @@ def main():
                        'association': args.assoc if args.workload == 'c3' else None,
                        'detection_frames_per_gpu': per_rank, 'tiles_per_frame': n_tiles,
                        'weights': 'random-init (synth seed 42)', 'parallelism': f'frame-sharded x{world}',
+                       'input': 'hbm_resident' if args.input == 'hbm' else 'host_u16',
+                       'input_detail': ('preprocessed f32 frames resident in HBM when the timed region starts' if args.input == 'hbm' else
+                                        f'raw uint16 frames in pinned host memory: every pass copies them on a second stream (16-frame pieces) beside '
+                                        f'axt_preprocess_u16 and the CNN of the frames already there (chunks of 16, 32, 48, 64, then {args.chunk} frames; PCIe-inclusive)'),
                        'cnn_arith': args.arith,
                        'conv_algorithm': ('Winograd F(2x2,3x3), f32, for the six stride-1 conv blocks (2,4,5,7,8,10); direct for the two stride-2 blocks'
                                           if winograd else 'direct')},
@@ -269,6 +330,8 @@ def main():
                 out['other_association_variant'] = other
         if direct:
             out['other_arithmetic_variant'] = direct
+        if host_variant:
+            out['host_input_variant'] = host_variant
         if prof:
             # FLOPs a kernel EXECUTES on the matrix pipe: a Winograd block multiplies 16 times per 2x2 output tile, input and
             # output channel where the direct convolution multiplies 36 times (its transforms are additions on the vector pipe)
@@ -285,12 +348,19 @@ def main():
                 peak = PEAK_BF16_MFMA_TFLOPS / 6.0      # algorithmic f32 multiply-adds cost six bf16 products each
             out['roofline'] = {
                 'bound': 'mfma', 'kernel': dom['name'], 'achieved': round(achieved, 2), 'peak': round(peak, 1),
-                'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), **committed_traffic(dom['name'], winograd and dom['name'].split()[0] in wino_blocks),
+                'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
+                **committed_counters(table, dom['name'], winograd, wino_blocks, cnn_ms),
                 'avg_launch_ms': round(dom['ms'] / max(dom['launches'], 1), 4),
                 'flops_per_launch': flops / max(dom['launches'], 1),
                 'flops': ('executed on the matrix pipe (Winograd: 16/36 of the direct convolution\'s); '
                           'direct_equivalent = the same launches priced as direct convolutions' if winograd else 'direct convolution'),
                 'direct_equivalent': round(dom['flops_per_tile'] * dom['tiles'] / (dom['ms'] * 1e-3) / 1e12, 2),
+                # SURVEY.md 8d prices the layer as a direct convolution (2 x Hout^2 x Cout x Cin x 9 per tile): that count over
+                # the same time, next to the executed one
+                'algorithmic': {'achieved': round(dom['flops_per_tile'] * dom['tiles'] / (dom['ms'] * 1e-3) / 1e12, 2),
+                                'frac': round(dom['flops_per_tile'] * dom['tiles'] / (dom['ms'] * 1e-3) / 1e12 / peak, 4),
+                                'flops_per_launch': dom['flops_per_tile'] * dom['tiles'] / max(dom['launches'], 1),
+                                'whole_cnn_frac': round(cnn_flops_direct / (cnn_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
                 'measured': 'HIP events around every launch of this kernel inside the timed region',
                 'whole_cnn': {'achieved': round(cnn_flops / (cnn_ms * 1e-3) / 1e12, 2),
                               'frac': round(cnn_flops / (cnn_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
@@ -307,6 +377,102 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def assoc_only(args):
+    """Association-only lines: the detections of a scene of MOVING growth cones (synth.synth_detections: ~n_alive cones
+    per frame that are born, move <= 10 px per frame, are missed 8 % of the time and die; 8 % clutter) are resident in HBM;
+    one step = AxonDetections.assign_ids(): observation costs, admissible arcs (GPU), the association (--assoc mcf: the
+    reference's global min-cost-flow tracker, host solve; hungarian: the frame-to-frame variant, GPU) and IDed_dets_all.
+    Verified outside the timed region: the flow tracker against the successive-shortest-path solver (same trajectories
+    and cost), the frame-to-frame variant against the oracle's."""
+    import axtrack_amd
+    from axtrack_amd import synth, params, hotpath as hp
+    from axtrack_amd.detections import _cost_units_on_device
+    F, size, alive = {'assoc-c3': (252, 512, 90), 'assoc-c4': (1020, 1024, 380)}[args.workload]
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    d = synth.synth_detections(F, size, size, n_alive=alive, seed=0)
+    P = params.load_parameters()
+    P['ASSOCIATION'] = args.assoc
+    P['MCF_MAX_FLOW'] = 100000                      # (the deployed 450 is for the example's field of view; config 4 holds more cones)
+    tl = axtrack_amd.Timelapse(torch.zeros((5, size, size)), name='assoc', device=dev)
+    cd, cx, cy, cc = (torch.from_numpy(d[k]).to(dev) for k in ('conf', 'x', 'y', 'count'))
+
+    def step():
+        ad = axtrack_amd.AxonDetections(None, tl, P, None)
+        ad.set_detections(cd, cx, cy, cc)
+        ad.assign_ids(None, None)
+        return ad
+    for _ in range(args.warmup):
+        ad = step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ad = step()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / args.steps
+    # the arc builder alone (HBM-bound integer work), with events on its stream
+    dmax, units = _cost_units_on_device(P, 500, dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    hp.build_arcs(cx, cy, cc, size, size, dmax, units)
+    e0.record()
+    for _ in range(5):
+        arcs = hp.build_arcs(cx, cy, cc, size, size, dmax, units)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    arcs_ms = e0.elapsed_time(e1) / 5
+    n_det, n_arcs = int(d['count'].sum()), int(arcs[1].numel())
+    arc_bytes = 12 * n_det * (1 + len(dmax)) + 15 * n_arcs        # DESIGN.md section 5: anchors read per (frame, gap), 15 B per admitted arc
+    ok, what = None, 'not checked'
+    if not args.no_verify:
+        if args.assoc == 'mcf':
+            os.environ['AXT_MCF_FORCE_SSP'] = '1'
+            ref = step()
+            del os.environ['AXT_MCF_FORCE_SSP']
+            ok = bool(np.array_equal(ref._track_flat, ad._track_flat) and ref.mcf_total_cost == ad.mcf_total_cost)
+            what = 'trajectories and total cost equal to the successive-shortest-path solver on the same network'
+        else:
+            from oracle import oracle as orc
+            dets = [(d['conf'][t, :d['count'][t]], d['x'][t, :d['count'][t]].astype(np.int64), d['y'][t, :d['count'][t]].astype(np.int64)) for t in range(F)]
+            trajs = orc.hungarian_assoc(dets, size, size, dict(orc.DEFAULTS))
+            frame_of = np.repeat(np.arange(F), d['count'])
+            offs = np.concatenate([[0], np.cumsum(d['count'])])
+            got = {}
+            for k, tid in enumerate(ad._track_flat):
+                if tid >= 0:
+                    got.setdefault(int(tid), []).append((int(frame_of[k]), int(k - offs[frame_of[k]])))
+            ok = [sorted(got[i]) for i in sorted(got)] == trajs
+            what = 'trajectories equal to the oracle (hungarian)'
+    # how well the association recovers the scene's cones: detections of one cone that share one identity
+    truth = np.concatenate([d['truth'][t, :d['count'][t]] for t in range(F)])
+    tr = ad._track_flat
+    both = (truth >= 0) & (tr >= 0)
+    purity = None
+    if both.any():
+        pairs = np.stack([truth[both], tr[both]], 1)
+        _, inv, cnts = np.unique(pairs, axis=0, return_inverse=True, return_counts=True)
+        best = {}
+        for (c_, _t), n_ in zip(np.unique(pairs, axis=0), cnts):
+            best[c_] = max(best.get(c_, 0), n_)
+        purity = round(sum(best.values()) / max(int((truth >= 0).sum()), 1), 4)
+    out = {'metric': f'frames/sec association only ({"global min-cost flow" if args.assoc == "mcf" else "frame-to-frame Hungarian"}), '
+                     f'{size}x{size}x{F + 4} scene of moving growth cones',
+           'value': round(F / dt, 2), 'unit': 'frames/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+           'ms_per_step': round(dt * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+           'dtype': 'int64 (integer arc costs); f64 observation costs', 'data': 'synthetic',
+           'config': {'workload': f'{args.workload}: association only -- {F} frames of {size}x{size}, ~{alive} moving cones per frame (born, '
+                                  f'<= 10 px per frame, missed 8 %, dying; 8 % clutter), detections resident in HBM',
+                      'association': args.assoc, 'input': 'detections_hbm_resident', 'detections': n_det, 'arcs': n_arcs},
+           'n_ids': ad.n_ids, 'cones_in_scene': int(len(np.unique(truth[truth >= 0]))), 'detections_of_a_cone_under_its_main_identity': purity,
+           'verified': ok, 'verify': what,
+           'roofline': {'bound': 'hbm', 'kernel': 'axt_build_arcs (count + fill passes)', 'achieved': round(arc_bytes / (arcs_ms * 1e-3) / 1e9, 2),
+                        'peak': 8000.0, 'unit': 'GB/s', 'frac': round(arc_bytes / (arcs_ms * 1e-3) / 1e9 / 8000.0, 5), 'traffic': None,
+                        'avg_launch_ms': round(arcs_ms, 4), 'bytes_per_launch': arc_bytes,
+                        'note': 'algorithmic bytes (12 B per detection and (frame, gap) + 15 B per admitted arc) over HIP-event time; the pass is '
+                                'latency-bound at this size; the flow solve itself is host work and has no roofline'},
+           'solver_threads': min(len(os.sched_getaffinity(0)), 16)}
+    print(json.dumps(out), flush=True)
 
 
 def launch_ranks(n):
@@ -393,23 +559,82 @@ def verify(args, ad, frames_host, sd, per_rank, world):
                        'seconds': round(time.perf_counter() - t0, 1)}}
 
 
-def committed_traffic(kernel_name, wino=False):
-    """roofline.traffic: HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
-    same command (profiles/*_traffic.json, written by profiles/summarize.py; the newest that matches the kernel), or
-    None if there is none."""
-    import glob
+def _profile_key(name):
+    """'conv2 40>80 +pool' (bench table) / 'conv3x3_wino<40->80,s1,pool>' / 'conv<40->80,s1,pool>' (profiles) -> ('40>80', pool?)"""
     import re
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_traffic.json'))):
-        t = json.load(open(f))
-        m = re.search(r'<(\d+)->(\d+)', t.get('kernel', ''))
-        if m and f'{m.group(1)}>{m.group(2)}' in kernel_name.replace(' ', '') and ('wino' in t.get('kernel', '')) == bool(wino):
-            best = t
-    if best is None:
-        return {'traffic': None}
-    return {'traffic': best['hbm_bytes_per_launch'],
-            'traffic_detail': {'unit': 'HBM bytes per launch', 'source': 'profiles/ (rocprofv3 --pmc, separate passes)',
-                               'fetch_kb_raw': best['fetch_kb_raw'], 'write_kb': best['write_kb']}}
+    m = re.search(r'(\d+)-?>(\d+)', name)
+    return (f'{m.group(1)}>{m.group(2)}', 'pool' in name) if m else None
+
+
+def _read_profile_csv(path):
+    """Rows of a committed profiles/*.csv as dicts; older pmc summaries wrote kernel names with unquoted commas."""
+    import csv
+    lines = open(path).read().splitlines()
+    head = lines[0].split(',')
+    rows = []
+    for r in csv.reader(lines[1:]):
+        if len(r) > len(head):
+            r = [','.join(r[:len(r) - len(head) + 1])] + r[len(r) - len(head) + 1:]
+        rows.append(dict(zip(head, r)))
+    return rows
+
+
+def committed_counters(table, dom_name, winograd, wino_blocks, ms_per_step_cnn):
+    """The north-star counters of this command from the committed rocprofv3 passes (profiles/, newest set that holds
+    the dominant kernel): HBM bytes per launch and GB/s (FETCH_SIZE / WRITE_SIZE, separate --pmc passes, FETCH doubled per
+    the gfx950 correction) and the matrix-pipe busy fraction (SQ_VALU_MFMA_BUSY_CYCLES over GRBM_GUI_ACTIVE / 8 XCDs x 1024
+    SIMDs), for the dominant kernel and for the whole CNN of one pass. None where no committed profile matches."""
+    import glob
+    def is_wino(k):
+        return winograd and k.split()[0] in wino_blocks
+    def match(rows, bench_name):
+        key, want_wino = _profile_key(bench_name), is_wino(bench_name)
+        for r in rows:
+            k = r['kernel']
+            if 'conv' in k and _profile_key(k) == key and ('wino' in k) == want_wino:
+                return r
+        return None
+    out = {'traffic': None, 'hbm_gbps': None, 'mfma_busy': None}
+    kfiles = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_kernels.csv')), key=os.path.getmtime)
+    pfiles = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc.csv')), key=os.path.getmtime)
+    for f in reversed(kfiles):
+        rows = _read_profile_csv(f)
+        d = match(rows, dom_name)
+        if d is None or 'FETCH_SIZE_KB_per_launch' not in d:
+            continue
+        def nbytes(r):
+            return (2 * float(r['FETCH_SIZE_KB_per_launch']) + float(r['WRITE_SIZE_KB_per_launch'])) * 1024
+        out['traffic'] = int(nbytes(d))
+        whole = 0.0
+        for k in table:
+            r = match(rows, k['name'])
+            if r is not None and r['FETCH_SIZE_KB_per_launch'] not in ('nan', ''):
+                whole += nbytes(r) * k['launches']
+        out['hbm_gbps'] = {'kernel': round(nbytes(d) / (float(d['avg_us']) * 1e-6) / 1e9, 1),
+                           'whole_cnn': round(whole / (ms_per_step_cnn * 1e-3) / 1e9, 1),
+                           'peak': 8000.0, 'source': os.path.relpath(f, ROOT),
+                           'how': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per launch (FETCH x 2, gfx950) / rocprofv3 average launch '
+                                  'time (kernel); summed over the conv launches of a pass / the CNN time of this run (whole_cnn)'}
+        out['traffic_detail'] = {'unit': 'HBM bytes per launch', 'source': os.path.relpath(f, ROOT),
+                                 'fetch_kb_raw': float(d['FETCH_SIZE_KB_per_launch']), 'write_kb': float(d['WRITE_SIZE_KB_per_launch'])}
+        break
+    for f in reversed(pfiles):
+        rows = _read_profile_csv(f)
+        d = match(rows, dom_name)
+        if d is None:
+            continue
+        busy = lambda r: float(r['SQ_VALU_MFMA_BUSY_CYCLES']) / (float(r['GRBM_GUI_ACTIVE']) / 8 * 1024)
+        num = den = 0.0
+        for k in table:
+            r = match(rows, k['name'])
+            if r is not None:
+                num += float(r['SQ_VALU_MFMA_BUSY_CYCLES']) * k['launches']
+                den += float(r['GRBM_GUI_ACTIVE']) / 8 * 1024 * k['launches']
+        out['mfma_busy'] = {'kernel': round(busy(d), 3), 'whole_cnn_convs': round(num / den, 3) if den else None,
+                            'source': os.path.relpath(f, ROOT),
+                            'how': 'SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), rocprofv3 --pmc pass of this command'}
+        break
+    return out
 
 
 def cpu_baseline(args, sd, synth):

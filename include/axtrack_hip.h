@@ -92,6 +92,17 @@ int axt_cnn_forward_frames(axt_detector *det, const float *d_frames, int T_all, 
                            int t0, int n_frames, const int32_t *h_tile_yx, int n_tiles,
                            float *d_yolo, void *stream);
 
+/* The same forward pass in two calls, for input that arrives in chunks (Timelapse.from_host_u16: the reference's inference()
+ * starts from a host Timelapse and construct_tiles() moves it to the device, Timelapse.py:492-566): axt_cnn_front_frames runs
+ * conv blocks 0-5 (through the second max-pool) for the (frame, tile) items of frames t0 .. t0+n_frames-1 and leaves their
+ * features in the detector's batch buffer from item `item0` on; after the last chunk axt_cnn_back runs the remaining conv
+ * blocks and the three linear layers ONCE for items 0 .. n_items-1 (the first linear layer streams its 168 MB of weights per
+ * call, whatever the batch) and writes d_yolo [n_items,12,12,3]. item0 + items <= max_batch. Same results, bit for bit, as
+ * axt_cnn_forward_frames over the same items. Asynchronous. */
+int axt_cnn_front_frames(axt_detector *det, const float *d_frames, int T_all, int H, int W, int t0, int n_frames,
+                         const int32_t *h_tile_yx, int n_tiles, int item0, void *stream);
+int axt_cnn_back(axt_detector *det, int n_items, float *d_yolo, void *stream);
+
 /* FLOPs of one tile-forward (algorithmic: 2*M*N*K of the unpadded layers). */
 double axt_cnn_flops_per_tile(void);
 

@@ -23,6 +23,7 @@ for r in csv.DictReader(open(sys.argv[1])):
         continue
     a = acc[k][r['Counter_Name']]; a[0] += float(r['Counter_Value']); a[1] += 1
 names = sorted({c for v in acc.values() for c in v})
-print('kernel,' + ','.join(names))
+w = csv.writer(sys.stdout)                   # (kernel names hold commas: quoted)
+w.writerow(['kernel'] + names)
 for k, v in acc.items():
-    print(k + ',' + ','.join(f'{v[c][0] / max(v[c][1], 1):.0f}' for c in names))
+    w.writerow([k] + [f'{v[c][0] / max(v[c][1], 1):.0f}' for c in names])

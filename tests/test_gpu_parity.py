@@ -1814,3 +1814,39 @@ def test_bare_multi_gpu_bench_invocation_runs_two_ranks_on_this_gpu():
     b = json.loads(lines[0])
     assert b['n_gpus'] == 2 and b['value'] > 0 and b['tracks_identical_on_all_ranks'] is True and b['scaling'] == 'weak'
     assert b['config']['detection_frames_per_gpu'] == 32
+
+
+def test_host_resident_input_streams_to_the_same_detections(weights):
+    """Timelapse.from_host_u16: raw uint16 frames in (pinned) host memory, copied in chunks on a second stream beside the
+    preprocessing and the CNN of the previous chunk (the reference's inference() starts from a host Timelapse,
+    Timelapse.py:205-326,492-566). Frames, YOLO grids, detections and identities are those of the resident path
+    (prepare_input_data's preprocessing, then inference) bit for bit -- with chunks that do not divide the timelapse, with
+    a mask, and when one tile is empty at every time point (the streamed grids are then discarded)."""
+    import axtrack_amd
+    from axtrack_amd.timelapse import preprocess
+    rng = np.random.default_rng(11)
+    f0 = synth.synth_frames(41, 512, 1024, seed=21)
+    scale = params.DEPLOYED_STND_SCALER[1][0]
+    raw = np.clip((2.0 ** (f0 * scale) - 1.0) * 65535.0 + 121.0 * (f0 > 0), 0, 65535).astype(np.uint16)
+    model80 = axtrack_amd.Detector(weights, max_batch=80)      # the whole timelapse fits the batch buffer: conv front per chunk, the rest once
+    model32 = axtrack_amd.Detector(weights, max_batch=32)      # it does not: every chunk runs the whole network
+    P = params.load_parameters()
+    for mask, chunk, empty_tile, model in ((None, 16, False, model80), (synth.corridor_mask(512, 1024, 48, 128), 7, False, model32),
+                                           (None, 64, True, model80)):
+        r = raw.copy()
+        if empty_tile:
+            r[:, :, 512:] = 0
+        res = axtrack_amd.Timelapse(preprocess(r, mask, offset=121, clip=55, scale=scale), name='x', mask=mask)
+        ref = axtrack_amd.inference(res, model, None, P, None, None, None)
+        tl = axtrack_amd.Timelapse.from_host_u16(r, name='x', mask=mask, offset=121, clip=55, scale=scale, chunk_frames=chunk)
+        assert tl._pending
+        ad = axtrack_amd.inference(tl, model, None, P, None, None, None)
+        assert not tl._pending and torch.equal(tl.frames, res.frames)
+        assert ad.tile_yx == ref.tile_yx and len(ad.tile_yx) == (1 if empty_tile else 2)
+        assert torch.equal(ad._yolo, ref._yolo)
+        for a, b in zip(ad._host_dets(), ref._host_dets()):
+            assert np.array_equal(a, b)
+        assert np.array_equal(ad._track_flat, ref._track_flat) and ad.mcf_total_cost == ref.mcf_total_cost
+        # a second pass over the (now resident) object takes the ordinary path
+        ad2 = axtrack_amd.inference(tl, model, None, P, None, None, None)
+        assert torch.equal(ad2._yolo, ref._yolo)
