@@ -768,7 +768,7 @@ __device__ __forceinline__ void wino_body(const float *__restrict__ in, const fl
                 for (int bb = 0; bb < 2; ++bb) {
                     const f32x4 tb = y[a][bb] + bias_v[n];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) y[a][bb][j] = POOL ? (tb[j] > 0.f ? tb[j] : tb[j] * 0.1f) : fmaxf(tb[j], tb[j] * 0.1f);
+                    for (int j = 0; j < 4; ++j) y[a][bb][j] = fmaxf(tb[j], tb[j] * 0.1f);      // LeakyReLU(0.1) = max(t, 0.1 t)
                 }
             if constexpr (POOL) {
                 f32x4 r;

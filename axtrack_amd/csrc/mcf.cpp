@@ -501,8 +501,16 @@ struct Lsap {
     // order, so the result does not depend on the number of threads.
     std::vector<int32_t> cut_p, cut_q;        // leaf i = rows [cut_q[i], cut_p[i+1]), separator i = rows [cut_p[i], cut_q[i])
 
+    // Frame-sharded ranks (axt_mcf_shard_*): the leaves are dealt to the ranks in equal runs of `group` leaves; a rank solves
+    // its own run -- a subtree -- from the replicated network, the states of all subtrees are exchanged (one all-gather)
+    // and every rank then joins them: solve_tree with solved_group = group skips the subtrees and inserts the separators
+    // above them. The optimum is unique, so this is the single-process result.
+    int solved_group = 0;
+    static constexpr uint32_t kJoinStamp = 0x20000000u;          // above every stamp a subtree can have left in its columns
+
     uint32_t solve_tree(int a, int b)
     {
+        if (solved_group > 0 && b - a == solved_group && a % solved_group == 0) return kJoinStamp;
         if (b - a == 1) {
             const double t0 = now_ms();
             Search w(*this, 0);
@@ -539,10 +547,15 @@ struct Lsap {
         return hc == 0 ? 1 : (hc > 16 ? 16 : (int)hc);        // a GPU's share of the host's cores
     }
 
-    void run()
+    int leaves = 1, budget = 1;
+    double t_prep0 = 0, t_prep1 = 0;
+
+    // setup of the rows and the cuts of the time-block tree; `world` > 1: a leaf count that the ranks can share evenly
+    void prepare(int world = 1)
     {
         const double t0 = now_ms();
-        const int budget = thread_budget();
+        t_prep0 = t0;
+        budget = thread_budget();
         two_phase = getenv("AXT_MCF_TWO_PHASE") ? true : getenv("AXT_MCF_ONE_PHASE") ? false : n <= 120000;
         c.assign(2 * (size_t)n, Col{0, 0, -1, -1, -1, 0});
         rw.resize(n);
@@ -576,8 +589,8 @@ struct Lsap {
         // leaves: a power of two, at least kMinLeaf rows each, separators that do not run into the next cut
         int kMinLeaf = 1024;
         if (const char *e = getenv("AXT_MCF_MIN_LEAF")) kMinLeaf = atoi(e) >= 1 ? atoi(e) : 1;    // tests: force the tree on small networks
-        int leaves = 1;
-        while (leaves * 2 <= budget && n / (leaves * 2) >= kMinLeaf) leaves *= 2;
+        leaves = 1;
+        while (leaves * 2 <= budget * world && n / (leaves * 2) >= kMinLeaf) leaves *= 2;
         for (; leaves > 1; leaves /= 2) {
             cut_p.assign(leaves + 1, 0);
             cut_q.assign(leaves + 1, 0);
@@ -604,8 +617,44 @@ struct Lsap {
             cut_p.assign(2, 0); cut_q.assign(2, 0);
             cut_p[1] = cut_q[1] = n;
         }
-        const double t1 = now_ms();
+        t_prep1 = now_ms();
+    }
+
+    // ---- state of a subtree of leaves [a, b): its rows [cut_q[a], cut_p[b]) and the columns they can reach, in-slots
+    // [cut_q[a], cut_q[b]) and the rows' private exits. Layout: rows {u i64, col i32, arc i32}, in-slots {v i64, row i32, pad},
+    // exits {v i64, row i32, pad}.
+    int64_t state_bytes(int a, int b) const
+    {
+        const int64_t rows = cut_p[b] - cut_q[a], cols = cut_q[b] - cut_q[a];
+        return 16 * (rows + cols + rows);
+    }
+    void export_state(int a, int b, unsigned char *out) const
+    {
+        struct Rec { int64_t x; int32_t y, z; };
+        Rec *o = reinterpret_cast<Rec *>(out);
+        for (int k = cut_q[a]; k < cut_p[b]; ++k) *o++ = Rec{rw[k].u, rw[k].col, rw[k].arc};
+        for (int j = cut_q[a]; j < cut_q[b]; ++j) *o++ = Rec{c[j].v, c[j].row, 0};
+        for (int k = cut_q[a]; k < cut_p[b]; ++k) *o++ = Rec{c[n + k].v, c[n + k].row, 0};
+    }
+    void import_state(int a, int b, const unsigned char *in)
+    {
+        struct Rec { int64_t x; int32_t y, z; };
+        const Rec *o = reinterpret_cast<const Rec *>(in);
+        for (int k = cut_q[a]; k < cut_p[b]; ++k, ++o) { rw[k].u = o->x; rw[k].col = o->y; rw[k].arc = o->z; }
+        for (int j = cut_q[a]; j < cut_q[b]; ++j, ++o) { c[j].v = o->x; c[j].row = o->y; c[j].stamp = 0; }
+        for (int k = cut_q[a]; k < cut_p[b]; ++k, ++o) { c[n + k].v = o->x; c[n + k].row = o->y; c[n + k].stamp = 0; }
+    }
+
+    void run()
+    {
+        prepare();
         solve_tree(0, leaves);
+        second_phase();
+    }
+
+    void second_phase()
+    {
+        const double t0 = t_prep0, t1 = t_prep1;
         const double t2 = now_ms();
         size_t ends = 0;
         if (two_phase) {
@@ -649,9 +698,10 @@ struct Lsap {
 
 }  // namespace
 
-extern "C" int axt_mcf_solve(int n_det, const int64_t *h_obs, const int64_t *h_entry, const int64_t *h_exit,
-                             const int64_t *h_row_ptr, const int32_t *h_col, const int64_t *h_cost, int min_flow,
-                             int max_flow, int32_t *h_next, int32_t *h_track, int *n_tracks, int64_t *total_cost)
+// The whole solve; `solved`: an assignment-form solver that has already run (the frame-sharded path), or null.
+static int mcf_solve_impl(int n_det, const int64_t *h_obs, const int64_t *h_entry, const int64_t *h_exit,
+                          const int64_t *h_row_ptr, const int32_t *h_col, const int64_t *h_cost, int min_flow,
+                          int max_flow, int32_t *h_next, int32_t *h_track, int *n_tracks, int64_t *total_cost, Lsap *solved)
 {
     if (n_det < 0 || !h_row_ptr || !n_tracks || !total_cost || (n_det > 0 && (!h_obs || !h_entry || !h_exit || !h_next || !h_track))) {
         axt_set_error("axt_mcf_solve: null or negative argument");
@@ -679,12 +729,15 @@ extern "C" int axt_mcf_solve(int n_det, const int64_t *h_obs, const int64_t *h_e
     int F = 0;
     int64_t total = 0;
     bool done = false;
-    if (n_det > 0 && !getenv("AXT_MCF_FORCE_SSP")) {
+    if (n_det > 0 && (solved || !getenv("AXT_MCF_FORCE_SSP"))) {
         // fast path: optimum over all flow counts as an assignment problem
-        Lsap a;
-        a.n = n_det;
-        a.obs = h_obs; a.entry = h_entry; a.exitc = h_exit; a.row_ptr = h_row_ptr; a.cost = h_cost; a.col = h_col;
-        a.run();
+        Lsap local;
+        Lsap &a = solved ? *solved : local;
+        if (!solved) {
+            a.n = n_det;
+            a.obs = h_obs; a.entry = h_entry; a.exitc = h_exit; a.row_ptr = h_row_ptr; a.cost = h_cost; a.col = h_col;
+            a.run();
+        }
         for (int k = 0; k < n_det; ++k) {
             const int j = a.rw[k].col;
             if (j == k) continue;                                   // unused
@@ -743,3 +796,84 @@ extern "C" int axt_mcf_solve(int n_det, const int64_t *h_obs, const int64_t *h_e
     *total_cost = total;
     return AXT_OK;
 }
+
+extern "C" int axt_mcf_solve(int n_det, const int64_t *h_obs, const int64_t *h_entry, const int64_t *h_exit,
+                             const int64_t *h_row_ptr, const int32_t *h_col, const int64_t *h_cost, int min_flow,
+                             int max_flow, int32_t *h_next, int32_t *h_track, int *n_tracks, int64_t *total_cost)
+{
+    return mcf_solve_impl(n_det, h_obs, h_entry, h_exit, h_row_ptr, h_col, h_cost, min_flow, max_flow, h_next, h_track, n_tracks,
+                          total_cost, nullptr);
+}
+
+// ---- frame-sharded solve (include/axtrack_hip.h: axt_mcf_shard_*) ---------------------------------------------------
+struct axt_mcf_shard {
+    Lsap a;
+    int rank = 0, world = 1, group = 0;          // group = leaves per rank (0: the network is too small to share: every rank solves it whole)
+};
+
+extern "C" int axt_mcf_shard_begin(int n_det, const int64_t *h_obs, const int64_t *h_entry, const int64_t *h_exit,
+                                   const int64_t *h_row_ptr, const int32_t *h_col, const int64_t *h_cost, int rank, int world,
+                                   axt_mcf_shard **out, int64_t *state_bytes)
+{
+    if (n_det < 0 || !h_row_ptr || !out || !state_bytes || world < 1 || rank < 0 || rank >= world || (world & (world - 1)) ||
+        (n_det > 0 && (!h_obs || !h_entry || !h_exit))) {
+        axt_set_error("axt_mcf_shard_begin: bad argument (world must be a power of two, 0 <= rank < world)");
+        return AXT_EINVAL;
+    }
+    for (int k = 0; k < n_det; ++k)
+        for (int64_t e = h_row_ptr[k]; e < h_row_ptr[k + 1]; ++e)
+            if (h_col[e] <= k || h_col[e] >= n_det) {
+                axt_set_error("axt_mcf_shard_begin: arc %lld of detection %d does not point forward in time", (long long)e, k);
+                return AXT_EINVAL;
+            }
+    axt_mcf_shard *sh = new axt_mcf_shard;
+    sh->rank = rank; sh->world = world;
+    Lsap &a = sh->a;
+    a.n = n_det;
+    a.obs = h_obs; a.entry = h_entry; a.exitc = h_exit; a.row_ptr = h_row_ptr; a.cost = h_cost; a.col = h_col;
+    *state_bytes = 0;
+    if (n_det > 0) {
+        a.prepare(world);
+        sh->group = a.leaves >= world ? a.leaves / world : 0;
+        if (sh->group > 0) {
+            a.solve_tree(rank * sh->group, (rank + 1) * sh->group);           // this rank's run of leaves and the separators inside it
+            *state_bytes = a.state_bytes(rank * sh->group, (rank + 1) * sh->group);
+        }
+    }
+    *out = sh;
+    return AXT_OK;
+}
+
+extern "C" int axt_mcf_shard_export(const axt_mcf_shard *sh, void *h_state)
+{
+    if (!sh || (sh->group > 0 && !h_state)) { axt_set_error("axt_mcf_shard_export: null argument"); return AXT_EINVAL; }
+    if (sh->group > 0) sh->a.export_state(sh->rank * sh->group, (sh->rank + 1) * sh->group, static_cast<unsigned char *>(h_state));
+    return AXT_OK;
+}
+
+extern "C" int axt_mcf_shard_finish(axt_mcf_shard *sh, const void *const *h_states, const int64_t *h_state_bytes, int min_flow,
+                                    int max_flow, int32_t *h_next, int32_t *h_track, int *n_tracks, int64_t *total_cost)
+{
+    if (!sh || !n_tracks || !total_cost) { axt_set_error("axt_mcf_shard_finish: null argument"); return AXT_EINVAL; }
+    Lsap &a = sh->a;
+    if (a.n > 0) {
+        if (sh->group > 0) {
+            for (int r = 0; r < sh->world; ++r) {
+                if (r == sh->rank) continue;
+                if (!h_states || !h_states[r] || !h_state_bytes || h_state_bytes[r] != a.state_bytes(r * sh->group, (r + 1) * sh->group)) {
+                    axt_set_error("axt_mcf_shard_finish: the state of rank %d is missing or has the wrong size", r);
+                    return AXT_EINVAL;
+                }
+                a.import_state(r * sh->group, (r + 1) * sh->group, static_cast<const unsigned char *>(h_states[r]));
+            }
+            a.solved_group = sh->group;
+        }
+        a.solve_tree(0, a.leaves);               // the separators above the ranks' subtrees (everything, if the network was not shared)
+        a.solved_group = 0;
+        a.second_phase();
+    }
+    return mcf_solve_impl(a.n, a.obs, a.entry, a.exitc, a.row_ptr, a.col, a.cost, min_flow, max_flow, h_next, h_track, n_tracks,
+                          total_cost, a.n > 0 ? &a : nullptr);
+}
+
+extern "C" void axt_mcf_shard_free(axt_mcf_shard *sh) { delete sh; }

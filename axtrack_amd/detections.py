@@ -795,8 +795,13 @@ class AxonDetections(object):
         ee = float(P['MCF_ENTRY_EXIT_COST'])
         entry_int = _arc_cost_int_vec(np.full(n_det, ee), 0, k, 0)
         exit_int = _arc_cost_int_vec(np.full(n_det, ee), 1, k, 0)
-        res = hp.mcf_solve(obs_int, entry_int, exit_int, row_ptr[:n_det + 1].cpu().numpy(), col.cpu().numpy(),
-                           cost.cpu().numpy(), P['MCF_MIN_FLOW'], P['MCF_MAX_FLOW'])
+        net = (obs_int, entry_int, exit_int, row_ptr[:n_det + 1].cpu().numpy(), col.cpu().numpy(), cost.cpu().numpy())
+        if shard is not None and P.get('MCF_SHARDED_SOLVE', True):
+            # frame-sharded: every rank solves its run of time blocks, one all-gather joins the runs (sharded.solve_flow)
+            from . import sharded
+            res = sharded.solve_flow(*net, P['MCF_MIN_FLOW'], P['MCF_MAX_FLOW'], shard[2], self.device)
+        else:
+            res = hp.mcf_solve(*net, P['MCF_MIN_FLOW'], P['MCF_MAX_FLOW'])
         if res is None:
             print('Could not solve the graph for identity association; -> no IDed detections. Try narrowing '
                   'expected identities by updating parameters[`MCF_MIN_FLOW`, `MCF_MAX_FLOW`]. '

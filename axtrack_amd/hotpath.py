@@ -488,3 +488,40 @@ def mcf_solve(obs_int, entry_int, exit_int, row_ptr, col, cost_int, min_flow, ma
     if rc == 1:
         return None
     return nxt, track, int(n_tracks.value), int(total.value)
+
+
+class McfShard:
+    """One rank's part of the frame-sharded flow solve (axt_mcf_shard_*): begin() solves this rank's run of time blocks
+    and returns its state (uint8 array) for the all-gather; finish(states) joins the runs and returns what mcf_solve
+    returns. The network arrays are kept alive by this object."""
+
+    def __init__(self, obs_int, entry_int, exit_int, row_ptr, col, cost_int, rank, world):
+        self._lib = _lib.load()
+        self.n = len(obs_int)
+        self._keep = [np.ascontiguousarray(a, np.int64) for a in (obs_int, entry_int, exit_int, row_ptr)]
+        self._keep += [np.ascontiguousarray(col, np.int32), np.ascontiguousarray(cost_int, np.int64)]
+        h, nbytes = ctypes.c_void_p(), ctypes.c_int64(0)
+        k = self._keep
+        _lib.check(self._lib.axt_mcf_shard_begin(self.n, k[0].ctypes.data, k[1].ctypes.data, k[2].ctypes.data, k[3].ctypes.data,
+                                                 k[4].ctypes.data, k[5].ctypes.data, int(rank), int(world), ctypes.byref(h),
+                                                 ctypes.byref(nbytes)), 'axt_mcf_shard_begin')
+        self._h, self.rank, self.world = h, int(rank), int(world)
+        self.state = np.zeros(int(nbytes.value), np.uint8)
+        _lib.check(self._lib.axt_mcf_shard_export(self._h, self.state.ctypes.data), 'axt_mcf_shard_export')
+
+    def finish(self, states, min_flow, max_flow):
+        """states: list over ranks of uint8 arrays (this rank's own entry is not read)."""
+        states = [np.ascontiguousarray(s, np.uint8) for s in states]
+        ptrs = (ctypes.c_void_p * self.world)(*[s.ctypes.data if len(s) else None for s in states])
+        sizes = np.array([len(s) for s in states], np.int64)
+        nxt, track = np.empty(self.n, np.int32), np.empty(self.n, np.int32)
+        n_tracks, total = ctypes.c_int(0), ctypes.c_int64(0)
+        rc = _lib.check(self._lib.axt_mcf_shard_finish(self._h, ptrs, sizes.ctypes.data, int(min_flow), int(max_flow),
+                                                       nxt.ctypes.data, track.ctypes.data, ctypes.byref(n_tracks),
+                                                       ctypes.byref(total)), 'axt_mcf_shard_finish')
+        return None if rc == 1 else (nxt, track, int(n_tracks.value), int(total.value))
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h:
+            self._lib.axt_mcf_shard_free(h)

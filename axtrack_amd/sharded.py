@@ -5,7 +5,8 @@ frames and reads a +-2-frame input halo; no communication. Association is global
 per-frame detection lists (a few MB: latency-bound; RCCL over xGMI on GPUs, gloo on CPU in the tests) gives every
 rank all detections. The per-frame work of the association stays sharded -- the Hungarian variant's frame pairs
 (one MAX all-reduce joins the links), the flow tracker's arc rows with their path searches (all_gather_arcs) -- and
-only the deterministic integer-cost flow solve is replicated (a unique optimum: no broadcast needed).
+the flow solve itself is shared too (solve_flow: every rank solves its run of time blocks, one all-gather of the
+runs' states, then every rank joins them -- a unique optimum: no broadcast needed).
 """
 import time
 
@@ -92,6 +93,34 @@ def all_gather_arcs(row_ptr, col, length, gap, cost, n_det, group=None):
     w = allp[:, 1]
     return (g_row_ptr, (w & 0xffffffff).to(torch.int32), ((w >> 32) & 0xffff).to(torch.int16),
             ((w >> 48) & 0xff).to(torch.uint8), allp[:, 0].contiguous())
+
+
+def solve_flow(obs_int, entry_int, exit_int, row_ptr, col, cost_int, min_flow, max_flow, group=None, device=None):
+    """The global flow solve shared between the frame-sharded ranks (hotpath.McfShard / axt_mcf_shard_*): every rank solves
+    its own run of time blocks of the (replicated) network on its host threads, ONE all-gather exchanges the runs' states
+    (duals and matching, 16 bytes per row and column: ~10 MB for a 300 k-detection timelapse), and every rank joins them
+    through the separator rows and finishes. The optimum is unique, so all ranks end with the trajectories of a single-
+    process solve, and no broadcast is needed. Returns what hotpath.mcf_solve returns."""
+    import numpy as np
+    from . import hotpath as hp
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if world & (world - 1):
+        return hp.mcf_solve(obs_int, entry_int, exit_int, row_ptr, col, cost_int, min_flow, max_flow)    # not a power of two: replicated
+    shard = hp.McfShard(obs_int, entry_int, exit_int, row_ptr, col, cost_int, rank, world)
+    on_gpu = dist.get_backend(group) != 'gloo'
+    dev = device if on_gpu else torch.device('cpu')
+    sizes = torch.zeros((world,), dtype=torch.int64, device=dev)
+    sizes[rank] = len(shard.state)
+    _collective('flow_state_sizes_allreduce', lambda: dist.all_reduce(sizes, op=dist.ReduceOp.SUM, group=group))
+    sizes = sizes.cpu().numpy()
+    longest = max(int(sizes.max()), 1)
+    mine = torch.zeros((longest,), dtype=torch.uint8, device=dev)
+    mine[:len(shard.state)] = torch.from_numpy(shard.state).to(dev)
+    out = torch.empty((world * longest,), dtype=torch.uint8, device=dev)
+    _collective('flow_states_allgather', lambda: dist.all_gather_into_tensor(out, mine, group=group))
+    out = out.cpu().numpy()
+    states = [out[r * longest:r * longest + int(sizes[r])] for r in range(world)]
+    return shard.finish(states, min_flow, max_flow)
 
 
 def assemble_ided_dets_all(blocks, n_frames, reproduce_label_quirk=True):

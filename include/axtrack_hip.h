@@ -288,6 +288,26 @@ int axt_mcf_solve(int n_det, const int64_t *h_obs, const int64_t *h_entry, const
                   int min_flow, int max_flow,
                   int32_t *h_next, int32_t *h_track, int *n_tracks, int64_t *total_cost);
 
+/* The same solve shared between frame-sharded ranks (one process per GPU; AxonDetections.py:663-690 has one process). Every
+ * rank holds the whole network (the detections are all-gathered, the arcs rebuilt or gathered: DESIGN.md section 7) and calls
+ *   axt_mcf_shard_begin   -- sets the solver up and solves THIS rank's run of time blocks (1/world of the leaves of the
+ *                            time-block tree, on the rank's host threads); *state_bytes = size of the state to exchange;
+ *   axt_mcf_shard_export  -- writes that state (duals and matching of the rank's rows and columns) to h_state;
+ *   [one all-gather of the states between the ranks: torch.distributed, RCCL or gloo -- not this library's business]
+ *   axt_mcf_shard_finish  -- h_states[r] / h_state_bytes[r] = rank r's state (the own entry is ignored): joins the runs
+ *                            through the separator rows between them, runs the second phase, and returns exactly what
+ *                            axt_mcf_solve returns (the optimum is unique: every rank ends with the same trajectories);
+ *   axt_mcf_shard_free.
+ * world must be a power of two. The network arrays must stay valid from begin to finish. Host only. */
+typedef struct axt_mcf_shard axt_mcf_shard;
+int axt_mcf_shard_begin(int n_det, const int64_t *h_obs, const int64_t *h_entry, const int64_t *h_exit,
+                        const int64_t *h_row_ptr, const int32_t *h_col, const int64_t *h_cost, int rank, int world,
+                        axt_mcf_shard **out, int64_t *state_bytes);
+int axt_mcf_shard_export(const axt_mcf_shard *shard, void *h_state);
+int axt_mcf_shard_finish(axt_mcf_shard *shard, const void *const *h_states, const int64_t *h_state_bytes, int min_flow,
+                         int max_flow, int32_t *h_next, int32_t *h_track, int *n_tracks, int64_t *total_cost);
+void axt_mcf_shard_free(axt_mcf_shard *shard);
+
 /* ------------------------------------------------------------------------------------------
  * Frame-to-frame Hungarian association (BASELINE config 3; a build-side variant -- the reference
  * only runs the global tracker above, AxonDetections.py:663-690). Same cost model: linking a (frame t)

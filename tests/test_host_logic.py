@@ -346,3 +346,35 @@ def test_unstitched_tile_tables_equal_the_references(golden, name):
             assert str(d.conf.dtype) == 'Float32' and str(d.anchor_x.dtype) == 'Int64'
             n_checked += len(d)
     assert n_checked > 100
+
+
+@pytest.mark.parametrize('world', [2, 4, 8])
+def test_flow_solve_shared_between_ranks_in_one_process(world, monkeypatch):
+    """axt_mcf_shard_begin / export / finish without a process group: `world` shard objects stand for the ranks; each solves
+    its run of time blocks, the states are handed round, every one finishes with the single-process optimum -- on the
+    config-3 network, a scene of moving cones, a network too small to share (every rank then solves it whole) and an
+    infeasible one."""
+    from helpers import c3_network, moving_network
+    monkeypatch.setenv('AXT_MCF_THREADS', '2')
+    nets = [(moving_network(120, 512, 90, seed=3)[:6], 5, 100000, None), (moving_network(6, 256, 8, seed=1)[:6], 0, 1000, None),
+            (moving_network(6, 256, 8, seed=1)[:6], 500, 1000, 'infeasible')]
+    if world == 4:
+        nets.append((c3_network()[:6], 5, 450, None))
+    for net, lo, hi, what in nets:
+        ref = hp.mcf_solve(*net, lo, hi)
+        shards = [hp.McfShard(*net, r, world) for r in range(world)]
+        states = [s.state for s in shards]
+        for s in shards:
+            got = s.finish(states, lo, hi)
+            if what == 'infeasible':
+                assert ref is None and got is None
+                continue
+            assert got[2] == ref[2] and got[3] == ref[3] and np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    # a missing or mis-sized state is an error, not a wrong answer
+    net = moving_network(120, 512, 90, seed=3)[:6]
+    shards = [hp.McfShard(*net, r, 2) for r in range(2)]
+    if len(shards[1].state):
+        with pytest.raises(_lib.AxtError):
+            shards[0].finish([shards[0].state, shards[1].state[:-16]], 5, 100000)
+    with pytest.raises(_lib.AxtError):
+        hp.McfShard(*net, 0, 3)

@@ -82,6 +82,49 @@ def test_two_rank_gather_and_replicated_solve():
     assert res[0][2] >= 1
 
 
+def _flow_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), AXT_MCF_THREADS='2', AXT_MCF_MIN_LEAF='256')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from axtrack_amd import sharded, hotpath as hp
+    from helpers import moving_network
+    out = []
+    for F, alive, bounds in ((96, 60, (5, 100000)), (40, 30, (0, 12))):       # the second: the flow bound binds (fallback path)
+        net = moving_network(F, 512, alive, seed=5)[:6]
+        sharded.COLLECTIVE_MS = {}
+        res = sharded.solve_flow(*net, *bounds)
+        names = sorted(sharded.COLLECTIVE_MS)
+        sharded.COLLECTIVE_MS = None
+        ref = hp.mcf_solve(*net, *bounds)                                   # the single-process solve of the same network
+        same = res[2] == ref[2] and res[3] == ref[3] and np.array_equal(res[0], ref[0]) and np.array_equal(res[1], ref[1])
+        out.append((same, res[2], res[3], res[1].tobytes(), names))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_flow_solve():
+    """sharded.solve_flow (axt_mcf_shard_*): each of two ranks solves its run of time blocks, one all-gather exchanges the
+    states, both join them: trajectories and cost of the single-process solve on both ranks, also when the flow bound binds
+    and the solver falls back to successive shortest paths. Exactly two collectives (state sizes, states)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_flow_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for a, b in zip(res[0], res[1]):
+        assert a[0] and b[0], 'the sharded solve differs from the single-process solve'
+        assert a[1:4] == b[1:4], 'ranks disagree'
+        assert a[4] == ['flow_state_sizes_allreduce', 'flow_states_allgather']
+    assert res[0][0][1] > 10 and res[0][1][1] == 12
+
+
 def test_frame_block_partition():
     from axtrack_amd import sharded
     assert [sharded.frame_block(1008, r, 8) for r in (0, 7)] == [(0, 126), (882, 126)]
