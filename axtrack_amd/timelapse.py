@@ -5,6 +5,8 @@ path reads -- name, sizet/sizey/sizex, tilesize, mask, len() -- but keeps only w
 detector consumes: channel 0 of `X` (Timelapse.py:426-433; the two motion channels are all
 zeros for USE_MOTION_DATA='exclude', :366-367), context-padded: T_all = sizet + 2*context.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -142,7 +144,7 @@ class Timelapse:
     def stream_chunks(self):
         """Generator over the chunks of a host-resident timelapse. All H2D copies are enqueued at once on a copy stream, in
         pieces of 16 frames into a device buffer for the raw timelapse (2 bytes per pixel; no staging buffer to recycle), each
-        followed by an event. The compute (current) stream then takes the frames in chunks that GROW -- 16, 32, 48, 64 frames,
+        followed by an event. The compute (current) stream then takes the frames in chunks that GROW -- 16, 32, 48, 64, 80 frames,
         then `chunk_frames` -- so that the first kernels start after ~0.17 ms of copying while later chunks are large enough
         for full launches (PCIe delivers a 512x512 frame in 10.6 us, the detector needs ~14 us for it: the copies stay ahead
         of a schedule that grows no faster than that ratio allows; profiles/r03j_trace). Per chunk: wait for its last piece, the fused preprocessing pass into the frame buffer, the
@@ -152,21 +154,30 @@ class Timelapse:
         dev = self.frames.device
         T, H, W = self.frames.shape
         piece = 16
-        copy_stream = torch.cuda.Stream(device=dev)
+        ramp = tuple(int(v) for v in os.environ.get('AXT_STREAM_RAMP', '16,32,48,64,80').split(','))      # tuning knob (bench experiments)
+        copy_stream = _copy_stream(dev)
         compute = torch.cuda.current_stream(dev)
+        copy_stream.wait_stream(compute)                 # (the stream is shared between timelapses: start behind what is queued)
         d_raw = torch.empty((T, H, W), dtype=torch.int16, device=dev)
         landed = []
-        with torch.cuda.stream(copy_stream):
-            for a in range(0, T, piece):
-                d_raw[a:a + piece].copy_(self._host_raw[a:a + piece], non_blocking=True)
-                landed.append(copy_stream.record_event())
+
+        def enqueue_copies(upto):                       # pieces covering frames [.., upto)
+            with torch.cuda.stream(copy_stream):
+                while len(landed) * piece < min(upto, T):
+                    a0 = len(landed) * piece
+                    d_raw[a0:a0 + piece].copy_(self._host_raw[a0:a0 + piece], non_blocking=True)
+                    landed.append(copy_stream.record_event())
         m, off, lo, logc, scale = self._pre
         a, k = 0, 0
+        sizes = lambda kk: min(ramp[kk], self._chunk) if kk < len(ramp) else self._chunk
         while a < T:
-            n = min((16, 32, 48, 64)[k], self._chunk) if k < 4 else self._chunk
+            n = sizes(k)
             b = min(a + n, T)
             if T - b < piece:
                 b = T
+            # the copies of this chunk and of the next one are in the copy queue before this chunk's kernels are enqueued (all
+            # of them up front would keep the host busy for ~0.5 ms before the first kernel launch)
+            enqueue_copies(b + sizes(k + 1) + piece)
             compute.wait_event(landed[(b - 1) // piece])
             hp.preprocess_u16(d_raw[a:b], m, off, lo, logc, scale, out=self.frames[a:b])
             occ = None
@@ -221,6 +232,15 @@ class Timelapse:
 
 
 _PINNED = {}
+_COPY_STREAMS = {}
+
+
+def _copy_stream(dev):
+    """One copy stream per device, created once (creating a stream costs as much as a small kernel)."""
+    key = str(dev)
+    if key not in _COPY_STREAMS:
+        _COPY_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _COPY_STREAMS[key]
 
 
 def _pinned_bytes(n):

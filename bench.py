@@ -69,6 +69,7 @@ def main():
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='gloo only for rehearsals')
     ap.add_argument('--single-device', action='store_true',
                     help='rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)')
+    ap.add_argument('--replicated-solve', action='store_true', help='N > 1, --assoc mcf: every rank solves the whole flow problem (round 2) instead of sharing it')
     ap.add_argument('--launch-check', action='store_true',
                     help='no GPU work: every rank joins a gloo group, one all-reduce, rank 0 prints what it saw (tests the launcher)')
     args = ap.parse_args()
@@ -124,6 +125,7 @@ def main():
     P['DEVICE'] = str(dev)
     P['ASSOCIATION'] = args.assoc
     P['CNN_ARITH'] = args.arith
+    P['MCF_SHARDED_SOLVE'] = not args.replicated_solve
     winograd = args.arith in ('f32', 'f32_winograd')
     wino_blocks = ('conv2', 'conv4', 'conv5', 'conv7', 'conv8', 'conv10')  # the stride-1 blocks (Winograd in the default arithmetic)
     n_tiles = (-(-H // 512)) * (-(-W // 512))
@@ -310,7 +312,7 @@ def main():
                        'input': 'hbm_resident' if args.input == 'hbm' else 'host_u16',
                        'input_detail': ('preprocessed f32 frames resident in HBM when the timed region starts' if args.input == 'hbm' else
                                         f'raw uint16 frames in pinned host memory: every pass copies them on a second stream (16-frame pieces) beside '
-                                        f'axt_preprocess_u16 and the CNN of the frames already there (chunks of 16, 32, 48, 64, then {args.chunk} frames; PCIe-inclusive)'),
+                                        f'axt_preprocess_u16 and the CNN of the frames already there (chunks of 16, 32, 48, 64, 80, then {args.chunk} frames; PCIe-inclusive)'),
                        'cnn_arith': args.arith,
                        'conv_algorithm': ('Winograd F(2x2,3x3), f32, for the six stride-1 conv blocks (2,4,5,7,8,10); direct for the two stride-2 blocks'
                                           if winograd else 'direct')},
@@ -596,8 +598,8 @@ def committed_counters(table, dom_name, winograd, wino_blocks, ms_per_step_cnn):
                 return r
         return None
     out = {'traffic': None, 'hbm_gbps': None, 'mfma_busy': None}
-    kfiles = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_kernels.csv')), key=os.path.getmtime)
-    pfiles = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc.csv')), key=os.path.getmtime)
+    kfiles = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_kernels.csv')))           # r01_* < r02* < r03*: the newest round last
+    pfiles = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc.csv')))
     for f in reversed(kfiles):
         rows = _read_profile_csv(f)
         d = match(rows, dom_name)

@@ -1,5 +1,6 @@
-"""The line bench.py prints (as committed from the final GPU run, profiles/r01_k_bench.json) carries every field of the
-measurement contract, and the rocprofv3 summary committed beside it agrees with it on the dominant kernel."""
+"""The line bench.py prints (as committed from GPU runs: profiles/r01_k_bench.json, round 1, and profiles/r03z_bench.json,
+round 3) carries every field of the measurement contract, and the rocprofv3 summaries committed beside it agree with it on
+the dominant kernel; a bare `python bench.py --gpus N` starts its own ranks."""
 import csv
 import json
 import os
@@ -64,3 +65,30 @@ def test_a_failing_rank_fails_the_launcher():
         pytest.skip('the ranks would run')
     r = _bench('--gpus', '2', '--backend', 'gloo', '--single-device', '--steps', '1', '--warmup', '0')
     assert r.returncode != 0 and 'exited with code' in r.stderr and not r.stdout.strip()
+
+
+def test_round_3_line_carries_the_counters_and_the_input_kind():
+    """Round 3: roofline.mfma_busy / hbm_gbps / algorithmic next to the executed figure, config.input, the host-resident-input
+    variant in the default line and as a line of its own (profiles/r03z_*), and the rocprofv3 summaries they come from."""
+    b = json.load(open(os.path.join(ROOT, 'profiles', 'r03z_bench.json')))
+    assert b['verified'] is True and b['config']['input'] == 'hbm_resident' and b['vs_baseline'] is None
+    r = b['roofline']
+    assert 0.3 < r['mfma_busy']['kernel'] < 1 and r['mfma_busy']['source'].startswith('profiles/')
+    assert 0 < r['hbm_gbps']['kernel'] < r['hbm_gbps']['peak'] == 8000.0 and r['hbm_gbps']['whole_cnn'] > 0
+    assert abs(r['algorithmic']['achieved'] - r['direct_equivalent']) < 1e-6 and r['algorithmic']['frac'] > r['frac']
+    rows = list(csv.DictReader(open(os.path.join(ROOT, 'profiles', 'r03z_kernels.csv'))))
+    dom = max(rows, key=lambda q: float(q['total_us']))
+    assert 'wino<40->80' in dom['kernel']
+    assert abs(float(dom['avg_us']) / 1e3 - r['avg_launch_ms']) / r['avg_launch_ms'] < 0.08
+    pm = {q['kernel']: q for q in csv.DictReader(open(os.path.join(ROOT, 'profiles', 'r03z_pmc.csv')))}
+    k = pm['conv3x3_wino<40->80,s1,pool>']
+    busy = float(k['SQ_VALU_MFMA_BUSY_CYCLES']) / (float(k['GRBM_GUI_ACTIVE']) / 8 * 1024)
+    assert 0.6 < busy < 0.8
+    hv = b['host_input_variant']
+    h = json.load(open(os.path.join(ROOT, 'profiles', 'r03z_bench_host.json')))
+    assert h['config']['input'] == 'host_u16' and h['verified'] is True and 'PCIe-inclusive' in h['metric']
+    assert hv['detections'] > 0 and 0.5 < h['value'] / b['value'] < 1.0 and 0.5 < hv['value'] / b['value'] < 1.0
+    for w in ('assoc-c3', 'assoc-c4'):
+        for a in ('mcf', 'hungarian'):
+            q = json.load(open(os.path.join(ROOT, 'profiles', f'r03z_bench_{w}_{a}.json')))
+            assert q['verified'] is True and q['roofline']['bound'] == 'hbm' and q['config']['association'] == a
