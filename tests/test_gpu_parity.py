@@ -1850,3 +1850,24 @@ def test_host_resident_input_streams_to_the_same_detections(weights):
         # a second pass over the (now resident) object takes the ordinary path
         ad2 = axtrack_amd.inference(tl, model, None, P, None, None, None)
         assert torch.equal(ad2._yolo, ref._yolo)
+
+
+def test_bench_lines_of_the_other_workloads_run_and_verify():
+    """bench.py --input host and --workload assoc-c3 (both association variants) at reduced length: one JSON line each with
+    the contract fields, `verified` true, the input kind named in config."""
+    import json, subprocess, sys
+    root = os.path.join(os.path.dirname(__file__), '..')
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    def run(*argv):
+        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), *argv], env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1
+        return json.loads(lines[0])
+    b = run('--input', 'host', '--frames', '44', '--steps', '2', '--warmup', '1', '--cpu-frames', '8')
+    assert b['verified'] is True and b['config']['input'] == 'host_u16' and b['roofline']['bound'] == 'mfma' and b['cpu_baseline']['value'] > 0
+    for assoc in ('mcf', 'hungarian'):
+        a = run('--workload', 'assoc-c3', '--assoc', assoc, '--steps', '2', '--warmup', '1')
+        assert a['verified'] is True and a['config']['input'] == 'detections_hbm_resident' and a['roofline']['bound'] == 'hbm'
+        assert a['n_ids'] > 20 and a['value'] > 0 and a['unit'] == 'frames/s'
