@@ -1297,8 +1297,8 @@ def test_inference_with_a_mask_that_changes_over_time(weights, quirk):
         assert np.array_equal(dists[k], ref['D'][k]), k
     # the path dictionary (astar_paths_cache='to', the default of inference()) under such a mask, all-ones frames included:
     # every path has the length the tracker used and is a neighbour walk between its two anchors
-    paths = ad.astar_dets_paths()
-    assert paths.keys() == dists.keys()
+    paths = ad.astar_dets_paths() if quirk else {}          # (tens of thousands of sparse matrices: once is enough)
+    assert not quirk or paths.keys() == dists.keys()
     cnt, _, x, y = ad._host_dets()
     n_paths = 0
     for lbl, rows in paths.items():
@@ -1308,9 +1308,10 @@ def test_inference_with_a_mask_that_changes_over_time(weights, quirk):
                 assert (pth is None) == (dists[lbl][i, j] >= 500)
                 if pth is not None:
                     assert pth.getnnz() == dists[lbl][i, j]
-                    assert pth.toarray()[y[t_bef, i], x[t_bef, i]] and pth.toarray()[y[t, j], x[t, j]]
+                    cells = set(zip(pth.row.tolist(), pth.col.tolist()))
+                    assert (y[t_bef, i], x[t_bef, i]) in cells and (y[t, j], x[t, j]) in cells
                     n_paths += 1
-    assert n_paths > 100
+    assert n_paths > 100 or not quirk
     # a [T,H,W] mask that never changes is a static mask
     tl2 = axtrack_amd.Timelapse(frames, name='synth', mask=np.stack([m0] * T_all))
     assert tl2.mask3d is None and np.array_equal(tl2.mask2d, m0)
@@ -1565,11 +1566,11 @@ def test_arcs_under_a_changing_mask_with_three_allowed_misses(weights):
     passes is ordered by (tail, gap, head) with fields wide enough for the gap (a 2-bit field used to spill into the tail and
     scramble the CSR rows): trajectories and cost equal the oracle's."""
     import axtrack_amd
-    T_all = 14
+    T_all = 10
     frames = synth.synth_frames(T_all, 512, 512, seed=37)
     m0 = synth.corridor_mask(512, 512, width=48, pitch=128)
     m1 = np.roll(m0, 31, axis=0)
-    mask = np.stack([m0] * 5 + [m1] * 5 + [m0] * 4)
+    mask = np.stack([m0] * 4 + [m1] * 3 + [m0] * 3)
     P = dict(params.load_parameters(), MCF_MAX_NUM_MISSES=3, MCF_MISS_RATE=0.9)
     model = axtrack_amd.Detector(weights, max_batch=16)
     ad = axtrack_amd.inference(axtrack_amd.Timelapse(frames, name='synth', mask=mask), model, None, P, None, None, None)
