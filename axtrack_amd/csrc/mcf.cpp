@@ -319,14 +319,17 @@ struct Lsap {
     }
 
     // false (concurrent mode only): the search met an older one and gave up; nothing was changed, insert the row again
-    bool insert_row(int i)
+    bool insert_row(int i) { return ticket > 0 ? insert_row_t<true>(i) : insert_row_t<false>(i); }
+
+    template <bool PAR>                       // (two instantiations: the serial one carries none of the claim logic)
+    bool insert_row_t(int i)
     {
         std::vector<Col> &c = L.c;
         std::vector<Row> &rw = L.rw;
         const std::vector<Arc> &arcs = L.arcs;
         const int n = L.n;
         heap.clear();
-        const bool par = ticket > 0;
+        constexpr bool par = PAR;
         bool dead = false;
         if (par) search = L.next_stamp.fetch_add(2, std::memory_order_relaxed);
         else search += 2;
