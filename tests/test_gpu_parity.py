@@ -1316,10 +1316,11 @@ def test_inference_with_a_mask_that_changes_over_time(weights, quirk):
     tl2 = axtrack_amd.Timelapse(frames, name='synth', mask=np.stack([m0] * T_all))
     assert tl2.mask3d is None and np.array_equal(tl2.mask2d, m0)
     # the frame-to-frame variant under the same masks (link costs from the per-mask passes of the arc builder)
-    adh = axtrack_amd.inference(tl, model, None, dict(P, ASSOCIATION='hungarian'), None, None, None)
-    refh = orc.inference(frames, weights, mask=mask, P=dict(orc.DEFAULTS, REPRODUCE_MASK_FRAME_QUIRK=quirk), yolo=list(yolo),
-                         assoc='hungarian')
-    assert tracks_from_next(np.zeros(len(adh._track_flat)), adh._track_flat, adh._offs) == refh['trajs']
+    if quirk:                                              # (the oracle searches every pair's paths again: once is enough)
+        adh = axtrack_amd.inference(tl, model, None, dict(P, ASSOCIATION='hungarian'), None, None, None)
+        refh = orc.inference(frames, weights, mask=mask, P=dict(orc.DEFAULTS, REPRODUCE_MASK_FRAME_QUIRK=quirk), yolo=list(yolo),
+                             assoc='hungarian')
+        assert tracks_from_next(np.zeros(len(adh._track_flat)), adh._track_flat, adh._offs) == refh['trajs']
     with pytest.raises(ValueError):
         axtrack_amd.Timelapse(frames, name='synth', mask=mask[:5])
 
