@@ -795,7 +795,7 @@ class AxonDetections(object):
         ee = float(P['MCF_ENTRY_EXIT_COST'])
         entry_int = _arc_cost_int_vec(np.full(n_det, ee), 0, k, 0)
         exit_int = _arc_cost_int_vec(np.full(n_det, ee), 1, k, 0)
-        net = (obs_int, entry_int, exit_int, row_ptr[:n_det + 1].cpu().numpy(), col.cpu().numpy(), cost.cpu().numpy())
+        net = (obs_int, entry_int, exit_int, *hp.to_host(row_ptr[:n_det + 1], col, cost))       # (pinned staging: 120 MB at config 4)
         if shard is not None and P.get('MCF_SHARDED_SOLVE', True):
             # frame-sharded: every rank solves its run of time blocks, one all-gather joins the runs (sharded.solve_flow)
             from . import sharded
