@@ -643,7 +643,10 @@ class AxonDetections(object):
         if getattr(self, '_hist', None) is None:
             frames, off = self.dataset.frames, 2
             if self.timepoint_subset != list(range(self.dataset.sizet)) and getattr(self, '_shard', None) is None:
-                frames, off = frames[[t + 2 for t in self.timepoint_subset]].contiguous(), 0     # the centre frames of the subset
+                # the centre frames of the subset. (The reference hands the tracker get_frame_and_truedets(i) with i the POSITION in
+                # the subset, AxonDetections.py:679-685 -- the image of dataset frame i, not of timepoint_subset[i]; only visible
+                # with MCF_VIS_SIM_WEIGHT > 0 under a subset, and not reproduced: the crops here belong to the detections.)
+                frames, off = frames[[t + 2 for t in self.timepoint_subset]].contiguous(), 0
             self._hist = hp.box_histograms(frames, self.d_x, self.d_y, self.d_count, t_offset=off,
                                            box=self.axon_box_size)
         return self._hist
