@@ -12,7 +12,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def run(rank, world, port, q, total_frames, seed):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    # (small time blocks, so that the flow solver's tree has leaves to share between the ranks on a 16-frame timelapse)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0', AXT_MCF_MIN_LEAF='64',
+                      AXT_MCF_THREADS='2')
     dist.init_process_group('gloo', rank=rank, world_size=world)
     import axtrack_amd
     from axtrack_amd import synth, params, sharded

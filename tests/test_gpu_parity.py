@@ -682,11 +682,12 @@ def test_path_cache_with_the_appearance_term_and_on_the_8_connected_grid(weights
 
 
 # ----------------------------------------------------------------------------------------- multi-GPU path
-def test_two_rank_frame_sharding(weights):
-    """Two ranks (gloo, both on cuda:0) each detect half of the frames, all-gather the detections, build the arcs /
-    solve the frame pairs of their own frames, exchange them and finish the association: both must equal the
-    single-process result bit for bit, in every association mode (Hungarian, flow, flow + appearance, flow on a
-    masked grid)."""
+@pytest.mark.parametrize('world', [2, 4])
+def test_two_rank_frame_sharding(weights, world):
+    """Two (and four) ranks (gloo, all on cuda:0) each detect their block of the frames, all-gather the detections, build the
+    arcs / solve the frame pairs of their own frames (and, for the flow tracker, their run of the solver's time blocks),
+    exchange them and finish the association: every rank must equal the single-process result bit for bit, in every
+    association mode (Hungarian, flow, flow + appearance, flow on a masked grid)."""
     import socket
     import torch.multiprocessing as mp
     import gpu_shard_worker
@@ -696,7 +697,7 @@ def test_two_rank_frame_sharding(weights):
         port = s.getsockname()[1]
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=gpu_shard_worker.run, args=(r, 2, port, q, total, seed)) for r in range(2)]
+    procs = [ctx.Process(target=gpu_shard_worker.run, args=(r, world, port, q, total, seed)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=300) for _ in procs)
@@ -716,10 +717,10 @@ def test_two_rank_frame_sharding(weights):
         else:
             ad = _run_inference(frames, weights, P, name='shard')
         ref = (ad.n_ids, ad._track_flat.tobytes(), ad.IDed_dets_all.to_numpy().tobytes(), list(ad.IDed_dets_all.index))
-        for r in (0, 1):
-            assert res[r][mode][:4] == ref, mode          # the table assembled from the two blocks is the global one
+        for r in range(world):
+            assert res[r][mode][:4] == ref, mode          # the table assembled from the ranks' blocks is the global one
             rows, cols = res[r][mode][4]
-            assert cols == 3 * (total // 2) and rows <= ad.n_ids
+            assert cols == 3 * (total // world) and rows <= ad.n_ids
 
 
 def test_two_rank_sharding_with_a_tile_that_is_empty_on_one_rank(weights):
