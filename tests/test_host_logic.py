@@ -378,3 +378,52 @@ def test_flow_solve_shared_between_ranks_in_one_process(world, monkeypatch):
             shards[0].finish([shards[0].state, shards[1].state[:-16]], 5, 100000)
     with pytest.raises(_lib.AxtError):
         hp.McfShard(*net, 0, 3)
+
+
+def test_moving_cone_scene_is_deterministic_and_obeys_the_detectors_rules():
+    """synth.synth_detections (association-only workloads): the same arguments give the same bytes; every frame is in
+    descending confidence, at or above the 0.55 floor, with no two detections closer than the NMS distance, anchors inside
+    the frame; cones live for several frames and move by at most max_step + 2 jitter per frame and axis."""
+    from axtrack_amd import synth
+    a = synth.synth_detections(40, 512, 512, n_alive=60, seed=9)
+    b = synth.synth_detections(40, 512, 512, n_alive=60, seed=9)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    c = synth.synth_detections(40, 512, 512, n_alive=60, seed=10)
+    assert not np.array_equal(a['x'], c['x'])
+    last = {}
+    moved = []
+    for t in range(40):
+        n = int(a['count'][t])
+        assert 20 < n <= a['conf'].shape[1]
+        conf, x, y, tr = a['conf'][t, :n], a['x'][t, :n].astype(np.int64), a['y'][t, :n].astype(np.int64), a['truth'][t, :n]
+        assert np.all(np.diff(conf.astype(np.float64)) <= 0) and conf.min() >= np.float32(0.55)
+        assert x.min() >= 0 and x.max() < 512 and y.min() >= 0 and y.max() < 512
+        d2 = (x[:, None] - x[None]) ** 2 + (y[:, None] - y[None]) ** 2
+        np.fill_diagonal(d2, 10 ** 9)
+        assert d2.min() >= 529
+        for i, cone in enumerate(tr):
+            if cone >= 0:
+                if cone in last and last[cone][0] == t - 1:
+                    moved.append(max(abs(int(x[i]) - last[cone][1]), abs(int(y[i]) - last[cone][2])))
+                last[int(cone)] = (t, int(x[i]), int(y[i]))
+    assert len(moved) > 500 and max(moved) <= 10 + 2 * 2 + 1
+
+
+def test_bench_reads_the_committed_counters_of_the_newest_round():
+    """bench.committed_counters: mfma_busy and hbm_gbps of the dominant kernel come from the newest committed profiles/*_pmc.csv
+    / *_kernels.csv that hold it (file names sort by round), also from summaries whose kernel names hold unquoted commas."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    table = [dict(name=n, launches=l) for n, l in (('conv0 5>20 s2', 2), ('conv1 20>40 s2', 2), ('conv2 40>80 +pool', 2), ('conv4 80>80', 2),
+                                                   ('conv5 80>80 +pool', 2), ('conv7 80>80', 1), ('conv8 80>80 +pool', 1), ('conv10 80>160', 1))]
+    wino = ('conv2', 'conv4', 'conv5', 'conv7', 'conv8', 'conv10')
+    got = bench.committed_counters(table, 'conv2 40>80 +pool', True, wino, 3.85)
+    assert got['mfma_busy']['source'] == 'profiles/r03z_pmc.csv' and 0.6 < got['mfma_busy']['kernel'] < 0.8
+    assert got['hbm_gbps']['source'] == 'profiles/r03z_kernels.csv' and got['traffic'] > 4e8
+    direct = bench.committed_counters(table, 'conv2 40>80 +pool', False, wino, 5.6)       # the direct kernels of the variant pass
+    assert direct['mfma_busy']['kernel'] > got['mfma_busy']['kernel']
+    old = bench._read_profile_csv(os.path.join(root, 'profiles', 'r02y_pmc.csv'))         # unquoted commas in the kernel column
+    assert any(r['kernel'] == 'conv3x3_wino<40->80,s1,pool>' and float(r['GRBM_GUI_ACTIVE']) > 0 for r in old)
