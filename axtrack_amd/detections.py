@@ -56,10 +56,11 @@ class AxonDetections(object):
         # per-frame accessor then index POSITIONS in this list, as the reference's do (its loops run over
         # range(len(self)) and look frames up through timepoint_subset).
         if timepoint_subset is None:
-            timepoint_subset = range(self.dataset.sizet)
-        self.timepoint_subset = [int(t) for t in timepoint_subset]
-        if any(t < 0 or t >= self.dataset.sizet for t in self.timepoint_subset):
-            raise ValueError(f'timepoint_subset must lie in [0, {self.dataset.sizet})')
+            self.timepoint_subset = range(self.dataset.sizet)      # (kept as a range: nothing per frame on the way to the first launch)
+        else:
+            self.timepoint_subset = [int(t) for t in timepoint_subset]
+            if any(t < 0 or t >= self.dataset.sizet for t in self.timepoint_subset):
+                raise ValueError(f'timepoint_subset must lie in [0, {self.dataset.sizet})')
         self.P = dict(parameters)
         self.device = dataset.device
         self.Sx, self.Sy, self.tilesize = parameters['SX'], parameters['SY'], parameters['TILESIZE']
@@ -67,7 +68,7 @@ class AxonDetections(object):
             raise ValueError('the HIP detector is specialised for TILESIZE=512, SX=SY=12')
         self.nms_min_dist = parameters.get('NON_MAX_SUPRESSION_DIST')
         self.conf_thr = parameters['BBOX_THRESHOLD']
-        self.all_conf_thrs = np.sort(np.append(np.arange(0.55, 1, .04), self.conf_thr)).round(2)
+        self.all_conf_thrs = _conf_thresholds(self.conf_thr)
         self.max_px_assoc_dist = hp.MAX_PX_ASSOC_DIST
         self.axon_box_size = hp.AXON_BOX_SIZE
         self.labelled = False
@@ -106,12 +107,16 @@ class AxonDetections(object):
             raise ValueError('the timelapse is empty (no tile has a non-zero pixel)')
         # the frames of timepoint_subset (AxonDetections.py:111), one launch sequence per run of consecutive frames
         sub = self.timepoint_subset
+        whole = isinstance(sub, range)
         runs, a = [], 0
-        for k in range(1, len(sub) + 1):
-            if k == len(sub) or sub[k] != sub[k - 1] + 1:
-                runs.append((sub[a], k - a))
-                a = k
-        if streamed is not None and streamed[0] == self.tile_yx and sub == list(range(self.dataset.sizet)):
+        if whole:
+            runs = [(0, len(sub))]
+        else:
+            for k in range(1, len(sub) + 1):
+                if k == len(sub) or sub[k] != sub[k - 1] + 1:
+                    runs.append((sub[a], k - a))
+                    a = k
+        if streamed is not None and streamed[0] == self.tile_yx and whole:
             self._yolo = streamed[1]                                 # computed chunk by chunk beside the copies
         else:
             parts = [self.model.detect_frames(frames, self.tile_yx, t0, n) for t0, n in runs]
@@ -642,7 +647,7 @@ class AxonDetections(object):
         computed once from the centre frames (AxonDetections.py:682-685)."""
         if getattr(self, '_hist', None) is None:
             frames, off = self.dataset.frames, 2
-            if self.timepoint_subset != list(range(self.dataset.sizet)) and getattr(self, '_shard', None) is None:
+            if not isinstance(self.timepoint_subset, range) and getattr(self, '_shard', None) is None:
                 # the centre frames of the subset. (The reference hands the tracker get_frame_and_truedets(i) with i the POSITION in
                 # the subset, AxonDetections.py:679-685 -- the image of dataset frame i, not of timepoint_subset[i]; only visible
                 # with MCF_VIS_SIM_WEIGHT > 0 under a subset, and not reproduced: the crops here belong to the detections.)
@@ -918,6 +923,16 @@ class AxonDetections(object):
 
 _COLUMNS_CACHE = {}
 _UNITS_CACHE = {}
+_THRS_CACHE = {}
+
+
+def _conf_thresholds(conf_thr):
+    """all_conf_thrs (AxonDetections.py:65-66): the thirteen thresholds of the detection metrics, read-only, per BBOX_THRESHOLD."""
+    if conf_thr not in _THRS_CACHE:
+        a = np.sort(np.append(np.arange(0.55, 1, .04), conf_thr)).round(2)
+        a.setflags(write=False)
+        _THRS_CACHE[conf_thr] = a
+    return _THRS_CACHE[conf_thr]
 
 
 def _cost_units_on_device(P, max_px, device):
