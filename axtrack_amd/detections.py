@@ -75,6 +75,19 @@ class AxonDetections(object):
         self.conn8 = bool(parameters.get('ASTAR_8_CONNECTED', False))
         self.reproduce_label_quirk = bool(parameters.get('REPRODUCE_FRAME_LABEL_QUIRK', True))
         self._det_tables = None
+        self._n_ids, self._n_tracks_dev = None, None
+
+    @property
+    def n_ids(self):
+        """Number of identities of the last association (None: adopted from a cache, ids are whatever the cache holds). The
+        frame-to-frame variant leaves the count on the device; it is fetched when somebody asks."""
+        if self._n_ids is None and self._n_tracks_dev is not None:
+            self._n_ids = int(self._n_tracks_dev.item())
+        return self._n_ids
+
+    @n_ids.setter
+    def n_ids(self, value):
+        self._n_ids, self._n_tracks_dev = value, None
 
     def __len__(self):
         """Number of detection frames (after a multi-GPU gather: of the whole timelapse)."""
@@ -759,7 +772,7 @@ class AxonDetections(object):
                                                  *(((shard[0], shard[1]), shard[2]) if shard else (None, None)),
                                                  mask=self._mask_dev() if (masked and ctab is None) else None, ctab=ctab)
             self._d_track, self._track_flat_cache = track, None       # host copies are made on first use only
-            self.n_ids, self.mcf_total_cost = int(n_tracks.item()), None
+            self._n_ids, self._n_tracks_dev, self.mcf_total_cost = None, n_tracks, None      # (the count stays on the device)
             return True
         if mode != 'mcf':
             raise ValueError(f"parameters['ASSOCIATION'] must be 'mcf' or 'hungarian', got {mode!r}")
@@ -876,7 +889,24 @@ class AxonDetections(object):
         shard = getattr(self, '_shard', None)
         if shard is not None:
             return self._ided_block(track, shard[0], shard[1])
+        key = (int(track.shape[0]), int(track.shape[1]))
+        if self._n_ids is None and self._n_tracks_dev is not None and key in _IDS_GUESS:
+            # The number of identities is still on the device, and fetching it first would hold the host -- and with it the
+            # launches below -- until the GPU has drained the pass. The table is built for the count of the previous pass over
+            # a timelapse of this shape (+ a margin) instead, the count travels with it, and rows beyond it are not shown; only
+            # if the guess turns out too small is the table built again.
+            rows = _IDS_GUESS[key]
+            got = _pinned_count()
+            got.copy_(self._n_tracks_dev, non_blocking=True)
+            vals, wait = hp.ided_table(track, self.d_conf, self.d_x, self.d_y, self.d_count, rows, self.reproduce_label_quirk, None, rows)
+            wait()
+            n = self._n_ids = int(got[0])
+            _IDS_GUESS[key] = (n // 64 + 2) * 64
+            if n <= rows:
+                return pd.DataFrame(vals[:n], index=_axon_index(np.arange(n)), columns=_ided_columns(len(self)), copy=False)
         n_ids, ids, id_row = self.n_ids, None, None
+        if n_ids is not None:
+            _IDS_GUESS[key] = (n_ids // 64 + 2) * 64
         if n_ids is None:                                           # adopted from a cache: ids may have gaps
             uniq = torch.unique(track[track >= 0])
             ids = uniq.cpu().numpy()
@@ -923,6 +953,14 @@ class AxonDetections(object):
 
 _COLUMNS_CACHE = {}
 _UNITS_CACHE = {}
+_IDS_GUESS = {}                 # (frames, capacity) -> rows to build IDed_dets_all for before the count is known
+_COUNT_BUF = []
+
+
+def _pinned_count():
+    if not _COUNT_BUF:
+        _COUNT_BUF.append(torch.zeros((1,), dtype=torch.int32, pin_memory=True))
+    return _COUNT_BUF[0]
 _THRS_CACHE = {}
 
 
