@@ -452,7 +452,7 @@ def detection_confusion(conf, x, y, count, gx, gy, gcount, thrs, min_dist=23, k_
     n_frames, cap = x.shape
     gcap = gx.shape[1]
     dev = x.device
-    th = torch.as_tensor(np.ascontiguousarray(thrs, np.float64)).to(dev)
+    th = torch.from_numpy(np.array(thrs, np.float64)).to(dev)            # (a copy: the cached thresholds are read-only)
     out = torch.zeros((n_frames, 3, len(th)), dtype=torch.int32, device=dev)
     fp = fn = None
     if k_mask >= 0:
