@@ -19,6 +19,7 @@ SIGNATURES = {
     'axt_detector_create': (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, ctypes.POINTER(c_void_p)]),
     'axt_detector_destroy': (None, [c_void_p]),
     'axt_detector_set_arith': (c_int, [c_void_p, c_int]),
+    'axt_detector_set_fused_front': (c_int, [c_void_p, c_int]),
     'axt_detector_device_bytes': (c_size_t, [c_void_p]),
     'axt_cnn_forward': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     'axt_cnn_forward_frames': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,

@@ -29,3 +29,10 @@ void axt_set_error(const char *fmt, ...);
 #define AXT_LAUNCH_CHECK() AXT_CHECK_HIP(hipGetLastError())
 
 static inline int axt_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// the kept tiles of a frame (tile row, tile column), passed to the kernels by value
+struct TileList { int n; short yx[2 * 256]; };
+
+// cnn_front.hip: conv blocks 0 + 1 in one launch: frames -> block 1's output [B,40,128,128]
+int axt_launch_conv_fused01(const float *in, const float *w0, const float *b0, const float *w1, const float *b1, float *out,
+                            int B, hipStream_t st, int Hf, int Wf, int t0, int tstep, int item0, int n_tiles, const TileList &tl);

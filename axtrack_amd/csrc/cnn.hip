@@ -52,7 +52,6 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned kOobOffset = 0x80000000u;       // byte offset beyond every descriptor's range: the load returns 0
 constexpr int kBufRecords = 0x7fffffff;
 
-struct TileList { int n; short yx[2 * 256]; };
 
 // Persistent workgroups: the grid is a multiple of 8 and every workgroup walks a strided list of work items
 // (batch item, channel group, 16x16 output tile). Workgroups are dealt round-robin over the 8 XCDs
@@ -1400,6 +1399,7 @@ struct axt_detector {
     unsigned *d_wb3[8] = {};    // conv blocks 2..6 packed for conv3x3_bf16x3 (allocated on the first switch to that arithmetic)
     std::vector<float> h_wfold[8];   // their BN-folded f32 weights [cout][cin][3][3], kept on the host for that packing
     float *d_wwino[8] = {};     // conv blocks 2..6 packed for conv3x3_wino (allocated on the first switch to that arithmetic)
+    int fuse01 = 1;             // conv blocks 0 and 1 in one kernel (conv_s2_fused); axt_detector_set_fused_front, AXT_FUSE_S2=0 at create
     int arith = 0;              // stride-1 blocks: 0 direct f32 MFMA | 1 bf16x3 (blocks 2..8) | 2 f32 Winograd F(2x2,3x3) (set by create)
     float *d_bconv[8] = {};     // folded bias
     float *d_wfc[3] = {};       // [K][Npad]
@@ -1695,6 +1695,12 @@ int run_front_a(axt_detector *d, const float *frames, int Hf, int Wf, int t0, in
                 const TileList &tl, int nb, int slot0, hipStream_t st)
 {
     int rc;
+    if (d->fuse01 && Wf % 4 == 0) {
+        // blocks 0 and 1 in one kernel (its 16-byte input pieces need aligned rows: other widths take the separate kernels)
+        ProfSpan ps(d, st, 0, nb);
+        if ((rc = axt_launch_conv_fused01(frames, d->d_wconv[0], d->d_bconv[0], d->d_wconv[1], d->d_bconv[1], d->d_act[1], nb, st,
+                                      Hf, Wf, t0, tstep, item0, n_tiles, tl))) return rc;
+    } else {
     {
         ProfSpan ps(d, st, 0, nb);
         const float *src = frames;
@@ -1728,6 +1734,7 @@ int run_front_a(axt_detector *d, const float *frames, int Hf, int Wf, int t0, in
     {
         ProfSpan ps(d, st, 1, nb);
         if ((rc = launch_conv_s2<20, 40, 4, false, 2>(d->d_act[0], d->d_wconv[1], d->d_bconv[1], d->d_act[1], 256, nb, st))) return rc;
+    }
     }
     {
         ProfSpan ps(d, st, 2, nb);
@@ -1897,6 +1904,7 @@ int axt_detector_create(const float *const *h_tensors, int n_tensors, int max_ba
         axt_set_error("device synchronize failed after upload");
         rc = AXT_EHIP;
     }
+    if (const char *e = getenv("AXT_FUSE_S2")) d->fuse01 = atoi(e) != 0;
     if (!rc) rc = axt_detector_set_arith(d, 2);        // default arithmetic: f32 Winograd for the stride-1 blocks
     if (rc) {
         axt_detector_destroy(d);
@@ -1928,6 +1936,13 @@ int axt_detector_set_arith(axt_detector *d, int mode)
         }
     }
     d->arith = mode;
+    return AXT_OK;
+}
+
+int axt_detector_set_fused_front(axt_detector *d, int fused)
+{
+    AXT_REQUIRE(d != nullptr && (fused == 0 || fused == 1), "axt_detector_set_fused_front: fused must be 0 or 1");
+    d->fuse01 = fused;
     return AXT_OK;
 }
 

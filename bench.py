@@ -315,7 +315,7 @@ def main():
                                         f'axt_preprocess_u16 and the CNN of the frames already there (chunks of 16, 32, 48, 64, 80, then {args.chunk} frames; PCIe-inclusive)'),
                        'cnn_arith': args.arith,
                        'conv_algorithm': ('Winograd F(2x2,3x3), f32, for the six stride-1 conv blocks (2,4,5,7,8,10); direct for the two stride-2 blocks'
-                                          if winograd else 'direct')},
+                                          if winograd else 'direct') + ('; the two stride-2 blocks fused into one kernel' if getattr(model, 'fused_front', False) else '')},
             'stages': stages,
             'detections': int(ad._host_dets()[0].sum()),
         }
@@ -372,7 +372,7 @@ def main():
                               'measured': 'one untimed pass with every launch bracketed'},
                 'kernels': [{'name': k['name'], 'ms_per_step': round(k['ms'], 4),
                              'tflops': round(executed(k) / max(k['ms'], 1e-9) / 1e9, 2)}
-                            for k in table],
+                            for k in table if k['launches']],
             }
         if world == 1 and args.cpu_frames > 0:
             out['cpu_baseline'] = cpu_baseline(args, sd, synth)
@@ -594,6 +594,10 @@ def committed_counters(table, dom_name, winograd, wino_blocks, ms_per_step_cnn):
         key, want_wino = _profile_key(bench_name), is_wino(bench_name)
         for r in rows:
             k = r['kernel']
+            if 'fused' in bench_name or 'fused' in k:          # conv_s2_fused <-> 'conv0+1 5>20>40 s2 fused'
+                if 'fused' in bench_name and 'fused' in k:
+                    return r
+                continue
             if 'conv' in k and _profile_key(k) == key and ('wino' in k) == want_wino:
                 return r
         return None

@@ -74,6 +74,12 @@ void axt_detector_destroy(axt_detector *det);
  * The modes agree to ~1e-6 on the grids and are not bit-identical to each other. Packed weights of modes 1 and 2 are built
  * on the first switch to them. Synchronous. */
 int axt_detector_set_arith(axt_detector *det, int mode);
+/* The two stride-2 conv blocks (0 and 1) of the detector: fused = 1 (the default at create) runs them as ONE kernel that
+ * keeps block 0's output in LDS (conv_s2_fused, cnn_front.hip) -- used whenever the frame width is a multiple of 4;
+ * fused = 0 runs the two separate kernels (conv3x3_s2_k1), which other widths take in either setting. The fused kernel
+ * sums block 1's products in another order: the grids of the two settings agree to f32 rounding (~1e-6), not bit for bit.
+ * Takes effect from the next forward pass. */
+int axt_detector_set_fused_front(axt_detector *det, int fused);
 /* bytes of device memory held by the handle (packed weights + activation workspace) */
 size_t axt_detector_device_bytes(const axt_detector *det);
 

@@ -1459,6 +1459,46 @@ def test_cnn_winograd_and_direct_arithmetic_against_oracle(golden, weights):
     assert np.array_equal(det.detect_frames(frames, [(0, 0)]).cpu().numpy(), grids['f32_direct'])
 
 
+def test_fused_front_kernel_against_the_separate_stride2_kernels_and_the_oracle(weights):
+    """axt_detector_set_fused_front: conv blocks 0 and 1 as ONE kernel (the default: block 0's output stays in LDS) against
+    the two separate stride-2 kernels and against the oracle's f32 forward pass -- on single tiles, on frames whose bottom
+    and right edges cut the tiles (tiles of every border kind: block 1's zero padding at the top and the left, the frame's
+    zero fill at the bottom and the right), on a batch that leaves the persistent workgroups with unequal tile counts, on
+    the tensor interface with hot corner pixels, and on a width that is not a multiple of 4 (which takes the separate
+    kernels in both settings: bit-equal). The fused kernel sums block 1 in another order: within 2e-5 of the separate
+    kernels on O(1) grids (measured 7e-7), and switching back restores the separate kernels' grids bit for bit."""
+    import axtrack_amd
+    det = axtrack_amd.Detector(weights, max_batch=64)
+    assert det.fused_front
+    cases = [(9, 512, 512, [(0, 0)]), (12, 700, 904, [(0, 0), (0, 1), (1, 0), (1, 1)]), (7, 300, 260, [(0, 0)]),
+             (8, 1100, 1032, [(0, 0), (1, 1), (2, 2), (0, 2), (2, 0)]), (18, 516, 520, [(0, 0), (0, 1), (1, 0), (1, 1)])]
+    for T, H, W, tiles in cases:
+        frames = synth.synth_frames(T, H, W, seed=3 + T)
+        fr = dev(frames)
+        det.set_fused_front(True)
+        yf = det.detect_frames(fr, tiles).cpu().numpy()
+        det.set_fused_front(False)
+        ys = det.detect_frames(fr, tiles).cpu().numpy()
+        assert np.isfinite(yf).all()
+        assert not np.array_equal(yf, ys) and np.abs(yf - ys).max() < 2e-5, (T, H, W)
+        for t in (0, T - 5):
+            ref = orc.cnn_forward(weights, orc.frame_tile_stack(frames, t, tiles))
+            np.testing.assert_allclose(yf[t], ref, atol=CNN_ATOL, rtol=CNN_RTOL)
+        det.set_fused_front(True)
+        assert np.array_equal(det.detect_frames(fr, tiles).cpu().numpy(), yf)        # deterministic
+    X = np.zeros((4, 5, 512, 512), np.float32)
+    X[1] = 1.0
+    for c, (yy, xx) in enumerate([(0, 0), (0, 511), (511, 0), (511, 511), (255, 256)]):
+        X[2, c, yy, xx] = 50.0
+    X[3] = synth.synth_frames(5, 512, 512, seed=9) * 3
+    np.testing.assert_allclose(det.detect_axons(dev(X)).cpu().numpy(), orc.cnn_forward(weights, X), atol=CNN_ATOL, rtol=CNN_RTOL)
+    fr = dev(synth.synth_frames(6, 530, 701, seed=17))                      # rows not 16-byte aligned: separate kernels
+    keep = hp.tile_occupancy(fr)
+    yf = det.detect_frames(fr, keep).cpu().numpy()
+    det.set_fused_front(False)
+    assert np.array_equal(det.detect_frames(fr, keep).cpu().numpy(), yf)
+
+
 def test_inference_with_direct_convolution_parameter(weights):
     """CNN_ARITH='f32_direct' through the whole path (the suite's other tests run the default arithmetic): detections and
     trajectories equal the oracle's given the grids the detector produced, grids within tolerance of the oracle's."""
