@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""conv_s2_fused (AXT_FUSE_S2=1) against the two separate stride-2 kernels: bit-equality of the YOLO grids on frames whose
+"""conv_s2_fused (Detector.set_fused_front) against the two separate stride-2 kernels: bit-equality of the YOLO grids on frames whose
 edges cut the tiles, then per-kernel HIP-event times on the headline workload."""
 import os, sys
 import numpy as np, torch
@@ -8,11 +8,9 @@ import axtrack_amd
 from axtrack_amd import synth
 
 def make(fused, mb):
-    if fused:
-        os.environ['AXT_FUSE_S2'] = '1'
-    else:
-        os.environ.pop('AXT_FUSE_S2', None)
-    return axtrack_amd.Detector(synth.synth_state_dict(42), max_batch=mb)
+    d = axtrack_amd.Detector(synth.synth_state_dict(42), max_batch=mb)
+    d.set_fused_front(fused)
+    return d
 
 ok = True
 for (T, H, W, tiles) in [(9, 512, 512, [(0, 0)]), (12, 700, 904, [(0, 0), (0, 1), (1, 0), (1, 1)]), (7, 300, 260, [(0, 0)]),

@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
-"""HIP-event time of the fused front kernel (AXT_FUSE_S2=1) for the library in AXT_LIB_PATH: 252 tile-forwards."""
+"""HIP-event time of the fused front kernel (the default) for the library in AXT_LIB_PATH: 252 tile-forwards."""
 import os, sys
-os.environ['AXT_FUSE_S2'] = '1'
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import axtrack_amd
