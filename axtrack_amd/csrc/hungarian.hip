@@ -16,6 +16,8 @@
 // optimum is unique and any exact LSAP solver (e.g. SciPy's linear_sum_assignment) returns the same matching.
 #include "axt_common.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr long HINF = 0x3fffffffffffffffL;
@@ -78,6 +80,13 @@ __device__ __forceinline__ void wave_argmin(long &key, int &idx)
 // NC > 0: launched with 256 threads. All four waves share the initialisation (every row's cheapest option: n x m link
 // costs at ~1 000 cycles each -- the 64-bit identity hash -- were 40 % of the kernel on one wave), then waves 1-3 leave
 // and wave 0 runs the searches alone.
+// Diagnostic build only (-DAXT_HUNG_STATS, profiles/hungarian_stats.py): per frame pair of the last gap-1 launch the
+// s_memtime ticks of the initialisation and of the searches, the number of searches and of search steps, n and m.
+#ifdef AXT_HUNG_STATS
+__device__ unsigned long long g_hung_stats[4096 * 8];
+#define HUNG_STAMP() __builtin_amdgcn_s_memtime()
+#endif
+
 template <int GAP, int NC>
 __global__ __launch_bounds__(NC > 0 ? 256 : 64) void hungarian_pair_kernel(
     const int *__restrict__ x, const int *__restrict__ y, const int *__restrict__ count,
@@ -109,6 +118,10 @@ __global__ __launch_bounds__(NC > 0 ? 256 : 64) void hungarian_pair_kernel(
     int *pbj = reinterpret_cast<int *>(pbest + 4 * cap);    // [4 cap] ... and their columns
     const bool cached = n <= cdim && m <= cdim;
 
+#ifdef AXT_HUNG_STATS
+    const unsigned long long st0 = HUNG_STAMP();
+    unsigned long long st1 = 0, n_search = 0, n_step = 0;
+#endif
     const long a0 = frame_off[t], b0 = frame_off[tb];
     for (int j = lane; j < m; j += nthr) {
         v[j] = 0;
@@ -203,6 +216,9 @@ __global__ __launch_bounds__(NC > 0 ? 256 : 64) void hungarian_pair_kernel(
     }
     __syncthreads();
 
+#ifdef AXT_HUNG_STATS
+    st1 = HUNG_STAMP();
+#endif
     if constexpr (NC > 0) {
         // ---- register-resident column state: column j = lane + 64*k lives in slot k of lane j % 64
         constexpr int NS = NC > 0 ? NC : 1;
@@ -216,6 +232,12 @@ __global__ __launch_bounds__(NC > 0 ? 256 : 64) void hungarian_pair_kernel(
             ok_r[k] = j < m && col_ok[j];
             rc_r[k] = j < m ? row4col[j] : -1;
         }
+        // The searches, once per way of getting a link cost: from the pair's cost matrix in LDS (the usual case) or computed
+        // (pairs too large for it). Two copies of the loop rather than a choice per column: with the choice inside, hipcc
+        // branches around every column slot and waits for each slot's LDS read on its own -- ~400 instructions and three
+        // LDS round trips per search step, 1 700 cycles (profiles/hungarian_stats.py).
+        auto searches = [&](auto cached_tag) {
+        constexpr bool CACHED = decltype(cached_tag)::value;
         for (int i = 0; i < n; ++i) {
             if (GAP == 2 && succ1[(long)t * cap + i] >= 0) continue;      // wave-uniform
             if (col4row[i] != -1) continue;                               // settled by the initialisation
@@ -223,7 +245,13 @@ __global__ __launch_bounds__(NC > 0 ? 256 : 64) void hungarian_pair_kernel(
             for (int k = 0; k < NS; ++k) { spc_r[k] = HINF; sc_r[k] = false; pred_r[k] = -1; }
             long minVal = 0, best_dummy = HINF;
             int cur = i, dummy_row = -1, n_sr = 0, sink = -1;             // sink >= 0: real column; -2: dummy of dummy_row
+#ifdef AXT_HUNG_STATS
+            ++n_search;
+#endif
             for (;;) {
+#ifdef AXT_HUNG_STATS
+                ++n_step;
+#endif
                 if (lane == 0) sr[n_sr] = cur;
                 ++n_sr;
                 const long ucur = u[cur];
@@ -236,7 +264,12 @@ __global__ __launch_bounds__(NC > 0 ? 256 : 64) void hungarian_pair_kernel(
 #pragma unroll
                 for (int k = 0; k < NS; ++k) {
                     const int j = lane + 64 * k;
-                    cst[k] = !ok_r[k] ? HINF : cached ? ccache[cur * cdim + j] : link_cost(cur, j);
+                    if constexpr (CACHED) {
+                        const long c = ccache[cur * cdim + min(j, cdim - 1)];     // columns >= m: not ok, whatever is read
+                        cst[k] = ok_r[k] ? c : HINF;
+                    } else {
+                        cst[k] = !ok_r[k] ? HINF : link_cost(cur, j);
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < NS; ++k) {
@@ -299,6 +332,9 @@ __global__ __launch_bounds__(NC > 0 ? 256 : 64) void hungarian_pair_kernel(
                 if (j < m) rc_r[k] = row4col[j];
             }
         }
+        };
+        if (cached) searches(std::true_type{});
+        else searches(std::false_type{});
     } else {
     for (int i = 0; i < n; ++i) {
             if (GAP == 2 && succ1[(long)t * cap + i] >= 0) continue;      // wave-uniform
@@ -359,6 +395,12 @@ __global__ __launch_bounds__(NC > 0 ? 256 : 64) void hungarian_pair_kernel(
             __syncthreads();
         }
     }
+#ifdef AXT_HUNG_STATS
+    if (GAP == 1 && lane == 0 && blockIdx.x < 4096) {
+        unsigned long long *o = g_hung_stats + blockIdx.x * 8;
+        o[0] = st1 - st0; o[1] = HUNG_STAMP() - st1; o[2] = n_search; o[3] = n_step; o[4] = n; o[5] = m;
+    }
+#endif
     for (int i = lane; i < n; i += 64) {
         const bool active = (GAP == 1) || (succ1[(long)t * cap + i] < 0);
         succ_out[(long)t * cap + i] = (active && col4row[i] >= 0) ? col4row[i] : -1;
@@ -654,3 +696,11 @@ extern "C" int axt_hungarian_assoc(const int32_t *d_x, const int32_t *d_y, const
     if (rc) return rc;
     return axt_chain_tracks(d_count, n_frames, cap, pred, work, d_track, d_n_tracks, stream);
 }
+
+#ifdef AXT_HUNG_STATS
+// diagnostic build: the statistics of the last gap-1 launch, u64 [4096 frame pairs][8]
+extern "C" int axt_debug_hung_stats(unsigned long long *h_out)
+{
+    return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_hung_stats), sizeof(unsigned long long) * 4096 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
