@@ -1386,9 +1386,16 @@ static const ConvPlan kPlan[8] = {{5, 2, 1}, {4, 3, 1}, {8, 5, 1}, {8, 5, 1}, {8
 // Tile-forwards per launch of the front layers. Measured on MI355X (252 tile-forwards): 16/32 -> 6.16 ms, 64/64 ->
 // 5.9 ms, 128/128 -> 5.8 ms, 256/256 -> 6.1 ms for the whole CNN: what matters is that every persistent workgroup of
 // the stride-2 kernels gets several tiles and that launch gaps amortise, not that the activations of one chunk fit
-// the Infinity Cache. 128 items of block-0 output are 0.67 GB.
-constexpr int kChunkA = 128;      // conv blocks 0-2
-constexpr int kChunkB = 128;      // conv blocks 3-4
+// the Infinity Cache. 128 items of block-0 output are 0.67 GB. Measured again with the fused front kernel (round 3, -DAXT_CHUNK_A/B):
+// 64/128 -> 3.69 ms, 128/128 -> 3.65 ms, 256/256 -> 3.61-3.68 ms: no difference beyond the run-to-run spread.
+#ifndef AXT_CHUNK_A
+#define AXT_CHUNK_A 128
+#endif
+#ifndef AXT_CHUNK_B
+#define AXT_CHUNK_B 128
+#endif
+constexpr int kChunkA = AXT_CHUNK_A;      // conv blocks 0-2
+constexpr int kChunkB = AXT_CHUNK_B;      // conv blocks 3-4
 constexpr int kFc1Split = 32, kFc2Split = 4, kFc3Split = 4;
 
 }  // namespace
