@@ -1,5 +1,5 @@
 // conv blocks 0 and 1 of the detector in one kernel (see cnn.hip for the rest of the network and for the two separate
-// stride-2 kernels this replaces when the detector is created with AXT_FUSE_S2=1).
+// stride-2 kernels this replaces by default: axt_detector_set_fused_front; AXT_FUSE_S2=0 at create keeps them).
 #include "axt_common.h"
 
 #include <type_traits>
@@ -25,20 +25,24 @@ constexpr int kBufRecords = 0x7fffffff;
 //   * the input arrives by LDS-DMA (buffer_load_dwordx4 ... lds): one channel = 35 rows x 34 16-byte segments = 20 pieces
 //     of 1 KiB, three per wave (four of them twice, so that every wave counts the same), rows as they lie in the frame.
 //     Segments outside the tile or the frame carry an out-of-range offset, for which the DMA writes zeros (measured:
-//     profiles/experiments/lds_dma_oob.hip). Four channel buffers: channels 0-3 of the NEXT tile are issued one piece at a
-//     time behind the MFMAs of block 1's phase (back to back a DMA instruction holds its wave for 100+ cycles), channel 4
-//     during phase A of channel 1, when channel 0's buffer is free again.
-//   * phase A (per input channel, one barrier each): block 0 on v_mfma_f32_4x4x1, all 20 channels of a pixel tile
-//     accumulate in registers over the 5 channels x 9 taps (k ascending: the same sums, in the same order, as
-//     conv3x3_s2_k1<5,20>). The region is cut into 9 row pairs x 2 column blocks of 2 x 32 pixels plus the single
-//     column X = 2 x0 - 1 (19 units over 8 waves: 3,3,3,2,2,2,2,2 -- 5,5,5,4 per SIMD). The stride-2 operand reads are
-//     2-way bank conflicts; with 10-15 MFMAs per 2-3 of them the LDS keeps up.
-//   * phase C (per chunk of 4 block-0 channels, one barrier each): the chunk's LeakyReLU'd values go to LDS, split into an
-//     even-column and an odd-column half per row (unit-stride reads), zero where block 1 pads; then block 1 on
+//     profiles/experiments/lds_dma_oob.hip). Four channel buffers, and the second chunk buffer for the fifth channel: the
+//     input of the NEXT tile is issued one piece at a time behind the MFMAs of block 1's phase (back to back a DMA
+//     instruction holds its wave for 100+ cycles) -- channel g behind chunk g, whose buffers are free by then.
+//   * phase A (one barrier in front: all five channels are in LDS; none inside): block 0 on v_mfma_f32_4x4x1, all 20
+//     channels of a pixel tile accumulate in registers over the 5 channels x 9 taps (k ascending: the same sums, in the
+//     same order, as conv3x3_s2_k1<5,20>). The region is cut into 9 row pairs x 2 column blocks of 2 x 32 pixels plus the
+//     single column X = 2 x0 - 1 (19 units over 8 waves: 3,3,3,2,2,2,2,2 -- 5,5,5,4 per SIMD). Per kernel row a pixel's
+//     three taps are one 4-byte and one aligned 8-byte LDS read. Measured: 0.67 of the 4x4x1 rate (what two waves per SIMD
+//     reach with this instruction elsewhere, too); on four waves with five units each 0.62.
+//   * phase C (per chunk of 4 block-0 channels, one barrier each): the chunk's LeakyReLU'd values go to LDS -- behind the
+//     MFMAs of the chunk before --, split into an even-column and an odd-column half per row (unit-stride reads), zero
+//     where block 1 pads; then block 1 on
 //     v_mfma_f32_16x16x4 -- K = the chunk's 4 channels, one MFMA per tap: wave = one output row = 2 pixel tiles of 16 x 3
 //     channel tiles of 16 (40 channels padded to 48). With the 4x4x1 shape a wave has 5 MFMAs per 3 operand reads here and
 //     the LDS, not the matrix pipe, bounds the phase (measured: 0.59 ms against 0.38 ms of MFMAs for 252 tile-forwards);
 //     the 16x16x4 shape spends 20 % more MFMA cycles on the padding and needs a sixth of the operand bytes.
+//   A tile's results leave after the first barrier of the next tile (the vmcnt(0) in front of that barrier covers the DMA
+//   pieces and must not wait for a young store).
 //   Block 1 sums its products in another order than conv3x3_s2_k1<20,40> (chunk, tap, then the 4 channels inside the
 //   instruction): results agree to f32 rounding, not bit for bit (tests/test_gpu_parity.py).
 // ------------------------------------------------------------------------------------------------
@@ -86,11 +90,12 @@ __global__ __launch_bounds__(512, 1) void conv_s2_fused(
 
     // work list: as conv3x3_s2_k1<FIRST>: every XCD a contiguous range of items, walked one band of tiles at a time
     constexpr int TILES_X = 128 / G::TW, NTILE = TILES_X * (128 / G::TH);
+    // (fewer than 8 items: one list for all workgroups -- an XCD's share of the items would be empty for most XCDs)
     const int xcd = blockIdx.x & 7;
-    const int it_begin = (int)((long)xcd * B / 8);
-    const int ni = (int)((long)(xcd + 1) * B / 8) - it_begin;
-    const int wstep = gridDim.x >> 3, wend = ni * NTILE;
-    int w = blockIdx.x >> 3;
+    const int it_begin = B >= 8 ? (int)((long)xcd * B / 8) : 0;
+    const int ni = B >= 8 ? (int)((long)(xcd + 1) * B / 8) - it_begin : B;
+    const int wstep = B >= 8 ? gridDim.x >> 3 : gridDim.x, wend = ni * NTILE;
+    int w = B >= 8 ? blockIdx.x >> 3 : blockIdx.x;
     if (w >= wend) return;
 
     // ---- roles ----
