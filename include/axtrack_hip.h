@@ -78,7 +78,8 @@ int axt_detector_set_arith(axt_detector *det, int mode);
  * keeps block 0's output in LDS (conv_s2_fused, cnn_front.hip) -- used whenever the frame width is a multiple of 4;
  * fused = 0 runs the two separate kernels (conv3x3_s2_k1), which other widths take in either setting. The fused kernel
  * sums block 1's products in another order: the grids of the two settings agree to f32 rounding (~1e-6), not bit for bit.
- * Takes effect from the next forward pass. */
+ * Takes effect from the next forward pass. (axt_detector_create starts with fused = 1 unless the environment holds
+ * AXT_FUSE_S2=0 -- for A/B runs of unmodified callers.) */
 int axt_detector_set_fused_front(axt_detector *det, int fused);
 /* bytes of device memory held by the handle (packed weights + activation workspace) */
 size_t axt_detector_device_bytes(const axt_detector *det);
