@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <stdio.h>
 #include <string.h>
 
@@ -29,6 +30,30 @@ void axt_set_error(const char *fmt, ...);
 #define AXT_LAUNCH_CHECK() AXT_CHECK_HIP(hipGetLastError())
 
 static inline int axt_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Launch attributes (hipFuncSetAttribute) and occupancy answers belong to the CURRENT device, not to the process: a
+// second device in one process (Detector(device='cuda:1')) must get its own. One of these per launcher remembers, per
+// device index, that the launcher's kernels are set up there (a bit per device; devices beyond 63 are set up on every
+// call). No other state survives a call, as include/axtrack_hip.h promises.
+struct AxtOncePerDevice {
+    std::atomic<uint64_t> done{0};
+    int dev = 0;
+    // true: the kernels of this launcher still need their attributes on the current device (call mark() afterwards)
+    bool pending()
+    {
+        if (hipGetDevice(&dev) != hipSuccess) dev = 64;
+        return dev < 0 || dev >= 64 || !(done.load(std::memory_order_acquire) >> dev & 1);
+    }
+    void mark() { if (dev >= 0 && dev < 64) done.fetch_or(1ull << dev, std::memory_order_release); }
+};
+template <typename K>
+static inline int axt_max_dynamic_lds(K kernel, int bytes, AxtOncePerDevice &once)
+{
+    if (!once.pending()) return AXT_OK;
+    AXT_CHECK_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    once.mark();
+    return AXT_OK;
+}
 
 // the kept tiles of a frame (tile row, tile column), passed to the kernels by value
 struct TileList { int n; short yx[2 * 256]; };

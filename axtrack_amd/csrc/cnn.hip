@@ -1557,11 +1557,8 @@ template <int CIN, bool POOL>
 int launch_conv_b3(const float *in, const unsigned *w, const float *bias, float *out, int Hin, int B, hipStream_t st)
 {
     auto kern = conv3x3_bf16x3<CIN, POOL>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        AXT_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GeoB3::LDS_B));
-        attr_set = true;
-    }
+    static AxtOncePerDevice once;                 // (per device: see axt_common.h)
+    if (int rc = axt_max_dynamic_lds(kern, (int)(GeoB3::LDS_B), once)) return rc;
     AXT_REQUIRE(Hin % GeoB3::TH == 0 && w != nullptr, "conv (bf16x3): map size %d not a multiple of the 32x16 tile, or weights not packed", Hin);
     AXT_REQUIRE((double)CIN * Hin * Hin * 4 < 2.0e9, "conv (bf16x3): map too large");
     const int nwork = (Hin / GeoB3::TH) * (Hin / GeoB3::TW) * B;
@@ -1606,11 +1603,8 @@ template <int CIN, bool POOL, int NG = 1>
 int launch_conv_wino(const float *in, const float *u, const float *bias, float *out, int Hin, int B, hipStream_t st)
 {
     auto kern = conv3x3_wino<CIN, POOL, NG>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        AXT_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GeoW::LDS_B));
-        attr_set = true;
-    }
+    static AxtOncePerDevice once;                 // (per device: see axt_common.h)
+    if (int rc = axt_max_dynamic_lds(kern, (int)(GeoW::LDS_B), once)) return rc;
     AXT_REQUIRE(Hin % 16 == 0 && u != nullptr, "conv (winograd): map size %d not a multiple of the 16x16 tile, or weights not packed", Hin);
     AXT_REQUIRE((double)CIN * Hin * Hin * 4 < 2.0e9, "conv (winograd): map too large");
     const int nwork = (Hin / 16) * (Hin / 16) * B * NG;
@@ -1626,11 +1620,8 @@ int launch_conv(const float *in, const float *w, const float *bias, float *out, 
     auto kern = conv3x3_mfma<CIN, COUT, POOL, CCH, NT>;
     using G = GeoS1<CCH>;
     constexpr size_t lds = (size_t)(((CCH * G::PLANE + 3) & ~3) + G::KROWS * npadw(NT)) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        AXT_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static AxtOncePerDevice once;                 // (per device: see axt_common.h)
+    if (int rc = axt_max_dynamic_lds(kern, (int)(lds), once)) return rc;
     AXT_REQUIRE(Hin % 16 == 0, "conv: map size %d not a multiple of the 16x16 tile", Hin);
     const int nwork = (Hin / 16) * (Hin / 16) * ngroups * B;
     hipLaunchKernelGGL(kern, dim3(nwork), dim3(256), lds, st, in, w, bias, out, Hin, ngroups, B);
@@ -1646,11 +1637,8 @@ int launch_conv_s2(const float *in, const float *w, const float *bias, float *ou
     auto kern = conv3x3_s2_k1<CIN, COUT, NPC, FIRST, PF, WGS>;
     using G = GeoS2<COUT>;
     constexpr size_t lds = (size_t)(4 * (NPC * G::PLANE + 40) + CIN * 9 * 4 * G::NGP + COUT) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        AXT_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static AxtOncePerDevice once;                 // (per device: see axt_common.h)
+    if (int rc = axt_max_dynamic_lds(kern, (int)(lds), once)) return rc;
     AXT_REQUIRE(Hin % 64 == 0, "conv: map size %d not a multiple of the tile", Hin);
     AXT_REQUIRE(!FIRST || Wf % 4 == 0, "conv: frame pitch %d not a multiple of 4", Wf);
     // buffer addressing: offsets inside one tile's source window and inside the output of one launch are 32-bit
@@ -1659,11 +1647,16 @@ int launch_conv_s2(const float *in, const float *w, const float *bias, float *ou
     TileList dummy;
     dummy.n = 0;
     const int nwork = (Hin / 2 / G::TH) * (Hin / 2 / G::TW) * B;
-    static int per_cu = 0;                      // resident workgroups per CU for this kernel (registers + LDS)
+    // resident workgroups per CU for this kernel (registers + LDS), asked of the device the launch goes to
+    static std::atomic<int> per_cu_of[64];
+    int dev = 0;
+    AXT_CHECK_HIP(hipGetDevice(&dev));
+    int per_cu = dev >= 0 && dev < 64 ? per_cu_of[dev].load(std::memory_order_relaxed) : 0;
     if (per_cu == 0) {
         int n = 0;
         AXT_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)kern, 256, lds));
         per_cu = n < 1 ? 1 : (n > 8 ? 8 : n);
+        if (dev >= 0 && dev < 64) per_cu_of[dev].store(per_cu, std::memory_order_relaxed);
     }
     hipLaunchKernelGGL(kern, dim3(persistent_grid(nwork, per_cu)), dim3(256), lds, st, in, w, bias, out, Hin, B, Hf, Wf,
                        t0, tstep, item0, n_tiles, tl ? *tl : dummy);

@@ -376,11 +376,8 @@ int axt_launch_conv_fused01(const float *in, const float *w0, const float *b0, c
                         int B, hipStream_t st, int Hf, int Wf, int t0, int tstep, int item0, int n_tiles, const TileList &tl)
 {
     constexpr size_t lds = (size_t)GeoF::LDS_FLOATS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        AXT_CHECK_HIP(hipFuncSetAttribute((const void *)conv_s2_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static AxtOncePerDevice once;                 // (per device: see axt_common.h)
+    if (int rc = axt_max_dynamic_lds(conv_s2_fused, (int)lds, once)) return rc;
     AXT_REQUIRE((double)Hf * Wf * 5 * 4 < 2.0e9, "conv: frames of %d x %d are too large", Hf, Wf);
     AXT_REQUIRE((double)B * 40 * 128 * 128 * 4 < 2.0e9, "conv: batch of %d is too large for one launch", B);
     const int nwork = B * (128 / GeoF::TH) * (128 / GeoF::TW);

@@ -346,12 +346,8 @@ int axt_decode_stitch_nms(const float *d_yolo, int n_frames, int n_tiles, const 
         return AXT_OK;
     }
     const size_t lds = (size_t)n_tiles * AXT_CELLS * 7 * 4;
-    static bool attr = false;
-    if (!attr) {
-        AXT_CHECK_HIP(hipFuncSetAttribute((const void *)decode_stitch_nms_kernel,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 28 * AXT_CELLS * 7 * 4));
-        attr = true;
-    }
+    static AxtOncePerDevice once;                 // (per device: see axt_common.h)
+    if (int rc = axt_max_dynamic_lds(decode_stitch_nms_kernel, 28 * AXT_CELLS * 7 * 4, once)) return rc;
     hipLaunchKernelGGL(decode_stitch_nms_kernel, dim3(n_frames), dim3(256), lds, (hipStream_t)stream, d_yolo, n_tiles,
                        tiles, conf_thr, min_dist * min_dist, cap, d_conf, d_x, d_y, d_count);
     AXT_LAUNCH_CHECK();

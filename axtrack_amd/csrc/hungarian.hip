@@ -571,15 +571,15 @@ static int hungarian_pairs_impl(const int32_t *d_x, const int32_t *d_y, const in
     int cdim = cap < 96 ? cap : 96;
     if (lds_base + (size_t)cdim * cdim * 8 > 160 * 1024) cdim = 0;
     const size_t lds = lds_base + (size_t)cdim * cdim * 8;
-    static bool attr = false;
-    if (!attr) {
+    static AxtOncePerDevice once;                 // (per device: see axt_common.h)
+    if (once.pending()) {
         AXT_CHECK_HIP(hipFuncSetAttribute((const void *)hungarian_pair_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         AXT_CHECK_HIP(hipFuncSetAttribute((const void *)hungarian_pair_kernel<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         AXT_CHECK_HIP(hipFuncSetAttribute((const void *)hungarian_pair_kernel<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         AXT_CHECK_HIP(hipFuncSetAttribute((const void *)hungarian_pair_kernel<1, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         AXT_CHECK_HIP(hipFuncSetAttribute((const void *)hungarian_pair_kernel<2, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         AXT_CHECK_HIP(hipFuncSetAttribute((const void *)hungarian_pair_kernel<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
+        once.mark();
     }
     // pass 2 of source frame t needs pass 1 of the pairs (t, t+1) and (t+1, t+2): pass 1 runs one frame further
     const int e1 = (max_gap == 2 ? t_end + 1 : t_end) < n_frames - 1 ? (max_gap == 2 ? t_end + 1 : t_end) : n_frames - 1;

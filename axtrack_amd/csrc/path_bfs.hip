@@ -852,11 +852,8 @@ int axt_masked_distance_table(const axt_grid *g, const int32_t *d_x, const int32
                              !getenv("AXT_PATH_NO_OFFMODE")) ? 1 : 0;
     const size_t lds = off_mode_ok ? lds4 : (size_t)3 * BFS_WH * BFS_WW * 4 + (size_t)max_gap * cap * 6 + 16;
     AXT_REQUIRE(lds <= 159 * 1024, "masked arcs: cap %d needs %zu bytes of LDS", cap, lds);
-    static bool attr = false;
-    if (!attr) {
-        AXT_CHECK_HIP(hipFuncSetAttribute((const void *)mask_bfs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-        attr = true;
-    }
+    static AxtOncePerDevice once;                 // (per device: see axt_common.h)
+    if (int rc = axt_max_dynamic_lds(mask_bfs_kernel, 159 * 1024, once)) return rc;
     hipLaunchKernelGGL(mask_bfs_kernel, dim3(cap, n_frames), dim3(BFS_THREADS), lds, st, d_x, d_y, d_count, d_src_count, n_frames, cap, g->d_bits,
                        g->d_label, g->H, g->W, g->Ww, g->conn8, max_dist, max_gap, d_dmax, d_Dtmp, (const unsigned int *)g->d_tight,
                        (const unsigned char *)g->d_off, g->n_comp, off_mode_ok);

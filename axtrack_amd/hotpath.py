@@ -495,7 +495,10 @@ def to_host(*tensors):
             buf = _HOST_STAGING[key] = torch.empty((max(n, 1) * 5 // 4 + 16,), dtype=t.dtype, pin_memory=True)
         buf[:n].copy_(t.reshape(-1), non_blocking=True)
         out.append(buf[:n].numpy().reshape(tuple(t.shape)))
-    torch.cuda.current_stream().synchronize()
+    # a non_blocking D2H copy runs on the current stream of the SOURCE tensor's device, which need not be the current
+    # device (Detector(device='cuda:1') without set_device): wait on every device that holds one of the tensors
+    for dev in {t.device for t in tensors if t.is_cuda}:
+        torch.cuda.current_stream(dev).synchronize()
     return out
 
 

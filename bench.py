@@ -517,7 +517,7 @@ def launch_ranks(n):
 
 def verify(args, ad, frames_host, sd, per_rank, world):
     """Self-check of the configuration that was just timed (same Detector, same launch shapes), outside the timed region,
-    against the CPU oracle: YOLO grids of 8 frames sampled across every front-layer launch within 2e-4 of the oracle's
+    against the CPU oracle: YOLO grids of 8 frames sampled across every front-layer launch within 1e-5 of the oracle's
     f32 forward pass; the detection lists of ALL of rank 0's frames bit-exact given those grids; the trajectories equal
     to the oracle's association (one GPU; with several ranks the association is checked through the cross-rank hash).
     The flow tracker's oracle is a Bellman-Ford solver (~40 s at config 3's size)."""
@@ -531,7 +531,7 @@ def verify(args, ad, frames_host, sd, per_rank, world):
     for t in sample:
         ref = orc.cnn_forward(sd, orc.frame_tile_stack(frames_host, t, ad.tile_yx))
         err = max(err, float(np.abs(yolo[t] - ref).max() / (1.0 + np.abs(ref).max())))
-    ok_cnn = err < 2e-4
+    ok_cnn = err < 1e-5                                    # 10x what the kernels deliver (4e-7 ... 1.5e-6)
     ref_dets = orc.detect_from_yolo(list(yolo), ad.tile_yx)
     cnt, conf, x, y = ad._host_dets()
     ok_det = True

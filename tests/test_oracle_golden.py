@@ -9,7 +9,7 @@ from helpers import golden_dets
 
 # CNN parity is by tolerance: the reference's conv/linear run through oneDNN/MKL with an
 # unspecified f32 summation order (model.py:50-53).
-CNN_ATOL, CNN_RTOL = 2e-4, 2e-4
+CNN_ATOL, CNN_RTOL = 1e-5, 1e-5
 
 
 def split(counts, *arrs):
