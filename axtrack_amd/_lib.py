@@ -59,11 +59,16 @@ SIGNATURES = {
                                    c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_int64), c_void_p]),
     'axt_mcf_solve': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                               c_void_p, c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int64)]),
+    'axt_mcf_solve_duals': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                    c_void_p, c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int64),
+                                    c_void_p, c_void_p, ctypes.POINTER(c_int64)]),
     'axt_mcf_shard_begin': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                     ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64)]),
     'axt_mcf_shard_export': (c_int, [c_void_p, c_void_p]),
     'axt_mcf_shard_finish': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, ctypes.POINTER(c_int),
                                      ctypes.POINTER(c_int64)]),
+    'axt_mcf_shard_finish_duals': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, ctypes.POINTER(c_int),
+                                           ctypes.POINTER(c_int64), c_void_p, c_void_p, ctypes.POINTER(c_int64)]),
     'axt_mcf_shard_free': (None, [c_void_p]),
     'axt_hungarian_assoc': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                     c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),

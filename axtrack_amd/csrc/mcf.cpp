@@ -702,9 +702,11 @@ struct Lsap {
 }  // namespace
 
 // The whole solve; `solved`: an assignment-form solver that has already run (the frame-sharded path), or null.
+// h_pot_u / h_pot_v / pot_t (all three or none): node potentials of the optimum (include/axtrack_hip.h, axt_mcf_solve_duals).
 static int mcf_solve_impl(int n_det, const int64_t *h_obs, const int64_t *h_entry, const int64_t *h_exit,
                           const int64_t *h_row_ptr, const int32_t *h_col, const int64_t *h_cost, int min_flow,
-                          int max_flow, int32_t *h_next, int32_t *h_track, int *n_tracks, int64_t *total_cost, Lsap *solved)
+                          int max_flow, int32_t *h_next, int32_t *h_track, int *n_tracks, int64_t *total_cost, Lsap *solved,
+                          int64_t *h_pot_u = nullptr, int64_t *h_pot_v = nullptr, int64_t *pot_t = nullptr)
 {
     if (n_det < 0 || !h_row_ptr || !n_tracks || !total_cost || (n_det > 0 && (!h_obs || !h_entry || !h_exit || !h_next || !h_track))) {
         axt_set_error("axt_mcf_solve: null or negative argument");
@@ -751,6 +753,17 @@ static int mcf_solve_impl(int n_det, const int64_t *h_obs, const int64_t *h_entr
         for (int k = 0; k < n_det; ++k)
             if (a.rw[k].col != k && s.pred[k] == NONE) { s.pred[k] = TERMINAL; total += h_entry[k]; ++F; }
         done = F >= min_flow && F <= max_flow;
+        if (done && h_pot_u) {
+            // The assignment duals as node potentials of the flow network, pi(S) = pi(T) = 0: pi(u_k) = entry_k + v(R_k),
+            // pi(v_k) = obs_k + entry_k - u(row k). Then the reduced cost of a transition arc is its row/column slack, of an
+            // entry arc -v(R_k) >= 0 (= 0 where R_k is unmatched: a track starts), of an exit arc the slack of X_k (<= 0 only
+            // where the row sits on it), of an observation arc u + v of (row k, R_k) <= 0 (= 0 where the detection is unused).
+            for (int k = 0; k < n_det; ++k) {
+                h_pot_u[k] = h_entry[k] + a.c[k].v;
+                h_pot_v[k] = h_obs[k] + h_entry[k] - a.rw[k].u;
+            }
+            *pot_t = 0;
+        }
         if (!done) {
             std::fill(s.pred.begin(), s.pred.end(), NONE);
             std::fill(s.succ.begin(), s.succ.end(), NONE);
@@ -764,10 +777,32 @@ static int mcf_solve_impl(int n_det, const int64_t *h_obs, const int64_t *h_entr
         s.par_arc.assign(2 * n_det + 2, -1);
         s.init_potentials();
         while (F < max_flow) {
-            if (!s.dijkstra()) break;
+            if (!s.dijkstra()) {
+                // no further path: the nodes the search reached move down together (reduced costs among them and out of
+                // the unreached part stay >= 0, no residual arc leaves them), which puts pi(T) - pi(S) at or above 0
+                if (h_pot_u) {
+                    int64_t far = 0;
+                    for (int32_t x : s.touched) if (s.dist[x] > far) far = s.dist[x];
+                    for (int32_t x : s.touched) s.pi[x] += s.dist[x] - far;
+                    const int64_t gap = s.pi[s.T] - s.pi[s.S];
+                    if (gap < 0) for (int32_t x : s.touched) s.pi[x] += gap;
+                }
+                break;
+            }
             const int64_t dT = s.dist[s.T];
             const int64_t path_cost = dT + s.pi[s.T] - s.pi[s.S];
-            if (F >= min_flow && path_cost >= 0) break;
+            if (F >= min_flow && path_cost >= 0) {
+                // optimal. Potentials for the certificate: pi += min(dist, theta) - theta keeps every residual reduced cost
+                // >= 0 for any 0 <= theta <= dT; theta = -(pi(T) - pi(S)) (the cost of the last path pushed, if negative)
+                // puts pi(T) - pi(S) at exactly 0, as an arc T -> S strictly inside its bounds requires.
+                if (h_pot_u) {
+                    int64_t theta = -(s.pi[s.T] - s.pi[s.S]);
+                    if (theta < 0) theta = 0;
+                    if (theta > dT) theta = dT;
+                    for (int32_t x : s.touched) s.pi[x] += (s.dist[x] < theta ? s.dist[x] : theta) - theta;
+                }
+                break;
+            }
             // Johnson update pi'[x] = pi[x] + min(dist[x], dT) keeps every residual reduced cost >= 0. Adding
             // the same constant to all potentials changes no reduced cost, so instead of +dT on the (many)
             // nodes the search never touched, the touched ones get min(dist, dT) - dT <= 0.
@@ -797,6 +832,10 @@ static int mcf_solve_impl(int n_det, const int64_t *h_obs, const int64_t *h_entr
     }
     *n_tracks = id;
     *total_cost = total;
+    if (h_pot_u && !done) {
+        for (int k = 0; k < n_det; ++k) { h_pot_u[k] = s.pi[s.U(k)] - s.pi[s.S]; h_pot_v[k] = s.pi[s.V(k)] - s.pi[s.S]; }
+        *pot_t = s.pi[s.T] - s.pi[s.S];
+    }
     return AXT_OK;
 }
 
@@ -806,6 +845,17 @@ extern "C" int axt_mcf_solve(int n_det, const int64_t *h_obs, const int64_t *h_e
 {
     return mcf_solve_impl(n_det, h_obs, h_entry, h_exit, h_row_ptr, h_col, h_cost, min_flow, max_flow, h_next, h_track, n_tracks,
                           total_cost, nullptr);
+}
+
+extern "C" int axt_mcf_solve_duals(int n_det, const int64_t *h_obs, const int64_t *h_entry, const int64_t *h_exit,
+                                   const int64_t *h_row_ptr, const int32_t *h_col, const int64_t *h_cost, int min_flow,
+                                   int max_flow, int32_t *h_next, int32_t *h_track, int *n_tracks, int64_t *total_cost,
+                                   int64_t *h_pot_u, int64_t *h_pot_v, int64_t *pot_t)
+{
+    if (n_det > 0 && (!h_pot_u || !h_pot_v || !pot_t)) { axt_set_error("axt_mcf_solve_duals: null potential array"); return AXT_EINVAL; }
+    int64_t dummy = 0;
+    return mcf_solve_impl(n_det, h_obs, h_entry, h_exit, h_row_ptr, h_col, h_cost, min_flow, max_flow, h_next, h_track, n_tracks,
+                          total_cost, nullptr, h_pot_u ? h_pot_u : &dummy, h_pot_v ? h_pot_v : &dummy, pot_t ? pot_t : &dummy);
 }
 
 // ---- frame-sharded solve (include/axtrack_hip.h: axt_mcf_shard_*) ---------------------------------------------------
@@ -854,8 +904,9 @@ extern "C" int axt_mcf_shard_export(const axt_mcf_shard *sh, void *h_state)
     return AXT_OK;
 }
 
-extern "C" int axt_mcf_shard_finish(axt_mcf_shard *sh, const void *const *h_states, const int64_t *h_state_bytes, int min_flow,
-                                    int max_flow, int32_t *h_next, int32_t *h_track, int *n_tracks, int64_t *total_cost)
+static int shard_finish_impl(axt_mcf_shard *sh, const void *const *h_states, const int64_t *h_state_bytes, int min_flow,
+                             int max_flow, int32_t *h_next, int32_t *h_track, int *n_tracks, int64_t *total_cost,
+                             int64_t *h_pot_u, int64_t *h_pot_v, int64_t *pot_t)
 {
     if (!sh || !n_tracks || !total_cost) { axt_set_error("axt_mcf_shard_finish: null argument"); return AXT_EINVAL; }
     Lsap &a = sh->a;
@@ -876,7 +927,21 @@ extern "C" int axt_mcf_shard_finish(axt_mcf_shard *sh, const void *const *h_stat
         a.second_phase();
     }
     return mcf_solve_impl(a.n, a.obs, a.entry, a.exitc, a.row_ptr, a.col, a.cost, min_flow, max_flow, h_next, h_track, n_tracks,
-                          total_cost, a.n > 0 ? &a : nullptr);
+                          total_cost, a.n > 0 ? &a : nullptr, h_pot_u, h_pot_v, pot_t);
+}
+
+extern "C" int axt_mcf_shard_finish(axt_mcf_shard *sh, const void *const *h_states, const int64_t *h_state_bytes, int min_flow,
+                                    int max_flow, int32_t *h_next, int32_t *h_track, int *n_tracks, int64_t *total_cost)
+{
+    return shard_finish_impl(sh, h_states, h_state_bytes, min_flow, max_flow, h_next, h_track, n_tracks, total_cost, nullptr, nullptr, nullptr);
+}
+
+extern "C" int axt_mcf_shard_finish_duals(axt_mcf_shard *sh, const void *const *h_states, const int64_t *h_state_bytes, int min_flow,
+                                          int max_flow, int32_t *h_next, int32_t *h_track, int *n_tracks, int64_t *total_cost,
+                                          int64_t *h_pot_u, int64_t *h_pot_v, int64_t *pot_t)
+{
+    if (sh && sh->a.n > 0 && (!h_pot_u || !h_pot_v || !pot_t)) { axt_set_error("axt_mcf_shard_finish_duals: null potential array"); return AXT_EINVAL; }
+    return shard_finish_impl(sh, h_states, h_state_bytes, min_flow, max_flow, h_next, h_track, n_tracks, total_cost, h_pot_u, h_pot_v, pot_t);
 }
 
 extern "C" void axt_mcf_shard_free(axt_mcf_shard *sh) { delete sh; }

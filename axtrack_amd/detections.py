@@ -817,12 +817,21 @@ class AxonDetections(object):
         entry_int = _arc_cost_int_vec(np.full(n_det, ee), 0, k, 0)
         exit_int = _arc_cost_int_vec(np.full(n_det, ee), 1, k, 0)
         net = (obs_int, entry_int, exit_int, *hp.to_host(row_ptr[:n_det + 1], col, cost))       # (pinned staging: 120 MB at config 4)
+        # parameters['MCF_CERTIFICATE'] (not a key of the reference): also return the node potentials that prove the optimum
+        # (axt_mcf_solve_duals) and keep them, with the network they refer to, in self.mcf_certificate
+        want_cert = bool(P.get('MCF_CERTIFICATE', False))
+        self.mcf_certificate = None
         if shard is not None and P.get('MCF_SHARDED_SOLVE', True):
             # frame-sharded: every rank solves its run of time blocks, one all-gather joins the runs (sharded.solve_flow)
             from . import sharded
-            res = sharded.solve_flow(*net, P['MCF_MIN_FLOW'], P['MCF_MAX_FLOW'], shard[2], self.device)
+            res = sharded.solve_flow(*net, P['MCF_MIN_FLOW'], P['MCF_MAX_FLOW'], shard[2], self.device, duals=want_cert)
         else:
-            res = hp.mcf_solve(*net, P['MCF_MIN_FLOW'], P['MCF_MAX_FLOW'])
+            res = hp.mcf_solve(*net, P['MCF_MIN_FLOW'], P['MCF_MAX_FLOW'], duals=want_cert)
+        if res is not None and want_cert:
+            self.mcf_certificate = dict(obs=net[0], entry=net[1], exit=net[2], row_ptr=net[3].copy(), col=net[4].copy(),
+                                        cost=net[5].copy(), next=res[0], track=res[1], total_cost=res[3], potentials=res[4],
+                                        min_flow=P['MCF_MIN_FLOW'], max_flow=P['MCF_MAX_FLOW'])
+            res = res[:4]
         if res is None:
             print('Could not solve the graph for identity association; -> no IDed detections. Try narrowing '
                   'expected identities by updating parameters[`MCF_MIN_FLOW`, `MCF_MAX_FLOW`]. '

@@ -506,9 +506,10 @@ def arc_cost_int(cost, kind, a, b):
     return int(_lib.load().axt_arc_cost_int(float(cost), int(kind), int(a), int(b)))
 
 
-def mcf_solve(obs_int, entry_int, exit_int, row_ptr, col, cost_int, min_flow, max_flow):
+def mcf_solve(obs_int, entry_int, exit_int, row_ptr, col, cost_int, min_flow, max_flow, duals=False):
     """MinCostFlowTracker.compute_trajectories (AxonDetections.py:690) on host arrays.
-    Returns (next i32 [n], track i32 [n], n_tracks, total_cost) or None when infeasible."""
+    Returns (next i32 [n], track i32 [n], n_tracks, total_cost) or None when infeasible; with duals=True a fifth element
+    (pot_u i64 [n], pot_v i64 [n], pot_t): the node potentials that certify the optimum (axt_mcf_solve_duals)."""
     n = len(obs_int)
     arrs = [np.ascontiguousarray(a, np.int64) for a in (obs_int, entry_int, exit_int, row_ptr)]
     col = np.ascontiguousarray(col, np.int32)
@@ -517,6 +518,14 @@ def mcf_solve(obs_int, entry_int, exit_int, row_ptr, col, cost_int, min_flow, ma
     track = np.empty(n, np.int32)
     n_tracks, total = ctypes.c_int(0), ctypes.c_int64(0)
     lib = _lib.load()
+    if duals:
+        pu, pv, pt = np.zeros(n, np.int64), np.zeros(n, np.int64), ctypes.c_int64(0)
+        rc = _lib.check(lib.axt_mcf_solve_duals(n, arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data,
+                                                arrs[3].ctypes.data, col.ctypes.data, cost_int.ctypes.data, int(min_flow),
+                                                int(max_flow), nxt.ctypes.data, track.ctypes.data, ctypes.byref(n_tracks),
+                                                ctypes.byref(total), pu.ctypes.data, pv.ctypes.data, ctypes.byref(pt)),
+                        'axt_mcf_solve_duals')
+        return None if rc == 1 else (nxt, track, int(n_tracks.value), int(total.value), (pu, pv, int(pt.value)))
     rc = _lib.check(lib.axt_mcf_solve(n, arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data,
                                       arrs[3].ctypes.data, col.ctypes.data, cost_int.ctypes.data, int(min_flow),
                                       int(max_flow), nxt.ctypes.data, track.ctypes.data, ctypes.byref(n_tracks),
@@ -545,13 +554,20 @@ class McfShard:
         self.state = np.zeros(int(nbytes.value), np.uint8)
         _lib.check(self._lib.axt_mcf_shard_export(self._h, self.state.ctypes.data), 'axt_mcf_shard_export')
 
-    def finish(self, states, min_flow, max_flow):
-        """states: list over ranks of uint8 arrays (this rank's own entry is not read)."""
+    def finish(self, states, min_flow, max_flow, duals=False):
+        """states: list over ranks of uint8 arrays (this rank's own entry is not read). duals: as mcf_solve."""
         states = [np.ascontiguousarray(s, np.uint8) for s in states]
         ptrs = (ctypes.c_void_p * self.world)(*[s.ctypes.data if len(s) else None for s in states])
         sizes = np.array([len(s) for s in states], np.int64)
         nxt, track = np.empty(self.n, np.int32), np.empty(self.n, np.int32)
         n_tracks, total = ctypes.c_int(0), ctypes.c_int64(0)
+        if duals:
+            pu, pv, pt = np.zeros(self.n, np.int64), np.zeros(self.n, np.int64), ctypes.c_int64(0)
+            rc = _lib.check(self._lib.axt_mcf_shard_finish_duals(self._h, ptrs, sizes.ctypes.data, int(min_flow), int(max_flow),
+                                                                 nxt.ctypes.data, track.ctypes.data, ctypes.byref(n_tracks),
+                                                                 ctypes.byref(total), pu.ctypes.data, pv.ctypes.data,
+                                                                 ctypes.byref(pt)), 'axt_mcf_shard_finish_duals')
+            return None if rc == 1 else (nxt, track, int(n_tracks.value), int(total.value), (pu, pv, int(pt.value)))
         rc = _lib.check(self._lib.axt_mcf_shard_finish(self._h, ptrs, sizes.ctypes.data, int(min_flow), int(max_flow),
                                                        nxt.ctypes.data, track.ctypes.data, ctypes.byref(n_tracks),
                                                        ctypes.byref(total)), 'axt_mcf_shard_finish')

@@ -95,17 +95,17 @@ def all_gather_arcs(row_ptr, col, length, gap, cost, n_det, group=None):
             ((w >> 48) & 0xff).to(torch.uint8), allp[:, 0].contiguous())
 
 
-def solve_flow(obs_int, entry_int, exit_int, row_ptr, col, cost_int, min_flow, max_flow, group=None, device=None):
+def solve_flow(obs_int, entry_int, exit_int, row_ptr, col, cost_int, min_flow, max_flow, group=None, device=None, duals=False):
     """The global flow solve shared between the frame-sharded ranks (hotpath.McfShard / axt_mcf_shard_*): every rank solves
     its own run of time blocks of the (replicated) network on its host threads, ONE all-gather exchanges the runs' states
     (duals and matching, 16 bytes per row and column: ~10 MB for a 300 k-detection timelapse), and every rank joins them
     through the separator rows and finishes. The optimum is unique, so all ranks end with the trajectories of a single-
-    process solve, and no broadcast is needed. Returns what hotpath.mcf_solve returns."""
+    process solve, and no broadcast is needed. Returns what hotpath.mcf_solve returns (duals: with the certificate)."""
     import numpy as np
     from . import hotpath as hp
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     if world & (world - 1):
-        return hp.mcf_solve(obs_int, entry_int, exit_int, row_ptr, col, cost_int, min_flow, max_flow)    # not a power of two: replicated
+        return hp.mcf_solve(obs_int, entry_int, exit_int, row_ptr, col, cost_int, min_flow, max_flow, duals=duals)    # not a power of two: replicated
     shard = hp.McfShard(obs_int, entry_int, exit_int, row_ptr, col, cost_int, rank, world)
     on_gpu = dist.get_backend(group) != 'gloo'
     dev = device if on_gpu else torch.device('cpu')
@@ -120,7 +120,7 @@ def solve_flow(obs_int, entry_int, exit_int, row_ptr, col, cost_int, min_flow, m
     _collective('flow_states_allgather', lambda: dist.all_gather_into_tensor(out, mine, group=group))
     out = out.cpu().numpy()
     states = [out[r * longest:r * longest + int(sizes[r])] for r in range(world)]
-    return shard.finish(states, min_flow, max_flow)
+    return shard.finish(states, min_flow, max_flow, duals=duals)
 
 
 def assemble_ided_dets_all(blocks, n_frames, reproduce_label_quirk=True):

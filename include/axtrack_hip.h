@@ -295,6 +295,20 @@ int axt_mcf_solve(int n_det, const int64_t *h_obs, const int64_t *h_entry, const
                   int min_flow, int max_flow,
                   int32_t *h_next, int32_t *h_track, int *n_tracks, int64_t *total_cost);
 
+/* axt_mcf_solve plus an optimality certificate (what a caller of the reference's tracker cannot get: libmot returns
+ * trajectories only, AxonDetections.py:690). Node potentials of the optimum, pi(S) = 0: h_pot_u[k] = pi(u_k), h_pot_v[k] = pi(v_k)
+ * (i64 [n_det] each), *pot_t = pi(T). With the reduced cost rc(x -> y) = cost + pi(x) - pi(y) of the arcs S -> u_k (entry),
+ * u_k -> v_k (observation), v_k -> T (exit), v_a -> u_b (transition) and T -> S (cost 0, between min_flow and max_flow units):
+ * rc >= 0 on every arc without flow, rc <= 0 on every arc that carries its unit, and for T -> S: pi(T) >= 0 unless the flow
+ * count sits at max_flow, pi(T) <= 0 unless it sits at min_flow. Together with a feasible flow (node-disjoint paths) these are
+ * the complementary-slackness conditions of the flow LP: checking them over all arcs -- O(arcs), no second solve -- proves that
+ * the returned trajectories are a minimum (tests/helpers.py: check_flow_certificate). Not written when AXT_INFEASIBLE. */
+int axt_mcf_solve_duals(int n_det, const int64_t *h_obs, const int64_t *h_entry, const int64_t *h_exit,
+                        const int64_t *h_row_ptr, const int32_t *h_col, const int64_t *h_cost,
+                        int min_flow, int max_flow,
+                        int32_t *h_next, int32_t *h_track, int *n_tracks, int64_t *total_cost,
+                        int64_t *h_pot_u, int64_t *h_pot_v, int64_t *pot_t);
+
 /* The same solve shared between frame-sharded ranks (one process per GPU; AxonDetections.py:663-690 has one process). Every
  * rank holds the whole network (the detections are all-gathered, the arcs rebuilt or gathered: DESIGN.md section 7) and calls
  *   axt_mcf_shard_begin   -- sets the solver up and solves THIS rank's run of time blocks (1/world of the leaves of the
@@ -313,6 +327,10 @@ int axt_mcf_shard_begin(int n_det, const int64_t *h_obs, const int64_t *h_entry,
 int axt_mcf_shard_export(const axt_mcf_shard *shard, void *h_state);
 int axt_mcf_shard_finish(axt_mcf_shard *shard, const void *const *h_states, const int64_t *h_state_bytes, int min_flow,
                          int max_flow, int32_t *h_next, int32_t *h_track, int *n_tracks, int64_t *total_cost);
+/* axt_mcf_shard_finish with the certificate of axt_mcf_solve_duals */
+int axt_mcf_shard_finish_duals(axt_mcf_shard *shard, const void *const *h_states, const int64_t *h_state_bytes, int min_flow,
+                               int max_flow, int32_t *h_next, int32_t *h_track, int *n_tracks, int64_t *total_cost,
+                               int64_t *h_pot_u, int64_t *h_pot_v, int64_t *pot_t);
 void axt_mcf_shard_free(axt_mcf_shard *shard);
 
 /* ------------------------------------------------------------------------------------------

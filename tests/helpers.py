@@ -117,3 +117,46 @@ def moving_network(n_frames, size, n_alive, seed=0, **kw):
     from axtrack_amd import synth
     d = synth.synth_detections(n_frames, size, size, n_alive=n_alive, seed=seed, **kw)
     return open_grid_network(d['count'], d['x'], d['y'], d['conf'], size, size)
+
+
+def check_flow_certificate(obs, entry, exit_, row_ptr, col, cost, nxt, track, total_cost, pots, min_flow, max_flow):
+    """Independent proof that (nxt, track) is a MINIMUM-cost flow of the tracker's network: primal feasibility (node-disjoint
+    paths along existing arcs, flow count within bounds), the stated total cost, and complementary slackness of the node
+    potentials `pots` = (pot_u, pot_v, pot_t) over ALL arcs (include/axtrack_hip.h, axt_mcf_solve_duals): reduced cost >= 0 on
+    every arc without flow, <= 0 on every arc with flow. O(arcs) numpy, no second solve. Returns a dict of counts; raises
+    AssertionError with the first violated condition."""
+    obs, entry, exit_, row_ptr, cost = (np.asarray(a, np.int64) for a in (obs, entry, exit_, row_ptr, cost))
+    col, nxt, track = np.asarray(col, np.int64), np.asarray(nxt, np.int64), np.asarray(track, np.int64)
+    pu, pv, pt = np.asarray(pots[0], np.int64), np.asarray(pots[1], np.int64), int(pots[2])
+    n = len(obs)
+    used = track >= 0
+    # ---- primal: every used detection has at most one successor / predecessor, successors are arcs of the network
+    has_next = nxt >= 0
+    assert not np.any(has_next & ~used), 'an unused detection has a successor'
+    assert np.all(used[nxt[has_next]]), 'a successor is an unused detection'
+    assert np.all(track[nxt[has_next]] == track[has_next]), 'a link joins two different trajectories'
+    indeg = np.bincount(nxt[has_next], minlength=n)
+    assert indeg.max(initial=0) <= 1, 'a detection has two predecessors'
+    start = used & (indeg == 0)
+    end = used & ~has_next
+    F = int(start.sum())
+    assert F == int(end.sum()) and F == (int(track.max()) + 1 if used.any() else 0), 'trajectory count'
+    assert min_flow <= F <= max_flow, f'flow count {F} outside [{min_flow}, {max_flow}]'
+    tail = np.repeat(np.arange(n, dtype=np.int64), np.diff(row_ptr))
+    on = nxt[tail] == col                                            # arcs that carry flow
+    assert int(on.sum()) == int(has_next.sum()), 'a link is not an arc of the network (or the network has parallel arcs)'
+    total = int(obs[used].sum() + entry[start].sum() + exit_[end].sum() + cost[on].sum())
+    assert total == int(total_cost), f'total cost {total_cost} stated, {total} recomputed'
+    # ---- dual: complementary slackness, arc class by arc class
+    def cs(rc, flow, what):
+        assert np.all(rc[~flow] >= 0), f'{what}: negative reduced cost on an arc without flow ({int((rc[~flow] < 0).sum())} arcs)'
+        assert np.all(rc[flow] <= 0), f'{what}: positive reduced cost on an arc with flow ({int((rc[flow] > 0).sum())} arcs)'
+    cs(entry - pu, start, 'entry arcs')
+    cs(obs + pu - pv, used, 'observation arcs')
+    cs(exit_ + pv - pt, end, 'exit arcs')
+    cs(cost + pv[tail] - pu[col], on, 'transition arcs')
+    if F < max_flow:
+        assert pt >= 0, f'one more trajectory would pay: pi(T) = {pt} < 0 with the flow count below max_flow'
+    if F > min_flow:
+        assert pt <= 0, f'one trajectory fewer would pay: pi(T) = {pt} > 0 with the flow count above min_flow'
+    return {'arcs': int(len(col)), 'arcs_with_flow': int(on.sum()), 'trajectories': F, 'used': int(used.sum())}

@@ -1766,7 +1766,8 @@ def test_baseline_configs_4_and_5_at_full_size(weights, cfg):
       * the arc rows (path lengths, admission, integer costs, global numbering) of sampled frame pairs -- every source
         detection of 4 frames on the open grid, 6 source detections of each of 4 frames on the masked grid (the oracle's
         masked search takes ~1 s per source),
-      * the solver's total cost recomputed from the product's trajectories, arcs and node costs."""
+      * the solver's total cost recomputed from the product's trajectories, arcs and node costs,
+      * and the optimality of those trajectories: the solver's node potentials satisfy complementary slackness on every arc."""
     import axtrack_amd
     T_all = {'c4': 1024, 'c5': 512}[cfg]
     frames = synth.synth_frames(T_all, 1024, 1024, seed=0)
@@ -1774,12 +1775,20 @@ def test_baseline_configs_4_and_5_at_full_size(weights, cfg):
     if mask is not None:
         frames *= mask[None].astype(np.float32)
     P = params.load_parameters()
+    P['MCF_CERTIFICATE'] = True
     model = axtrack_amd.Detector(weights, max_batch=1024)
     tl = axtrack_amd.Timelapse(frames, name=cfg, mask=mask)
     ad = axtrack_amd.inference(tl, model, None, P, None, None, None)
     F = T_all - 4
     cnt, conf, x, y = ad._host_dets()
     assert len(ad) == F == len(cnt) and len(ad.tile_yx) == 4 and cnt.min() > 0
+    # the optimality certificate of the flow solve at full size: complementary slackness of the returned node potentials
+    # over ALL arcs (11 M at config 4) -- the first proof, independent of the solver, that these trajectories are the minimum
+    from helpers import check_flow_certificate
+    cert = ad.mcf_certificate
+    proof = check_flow_certificate(cert['obs'], cert['entry'], cert['exit'], cert['row_ptr'], cert['col'], cert['cost'], cert['next'],
+                                   cert['track'], cert['total_cost'], cert['potentials'], cert['min_flow'], cert['max_flow'])
+    assert proof['trajectories'] == ad.n_ids and proof['arcs'] > 1000000 and np.array_equal(cert['track'], ad._track_flat)
     used = _size_independent_properties(ad, P, stride=23)
     assert used > 100 * F and ad.IDed_dets_all.shape == (ad.n_ids, 3 * F)
     # the CNN and the detection lists of 16 frames spread over every launch of the front layers

@@ -433,3 +433,72 @@ def test_bench_reads_the_committed_counters_of_the_newest_round():
     assert direct['mfma_busy']['kernel'] > got['mfma_busy']['kernel']
     old = bench._read_profile_csv(os.path.join(root, 'profiles', 'r02y_pmc.csv'))         # unquoted commas in the kernel column
     assert any(r['kernel'] == 'conv3x3_wino<40->80,s1,pool>' and float(r['GRBM_GUI_ACTIVE']) > 0 for r in old)
+
+
+def test_flow_certificate_proves_the_optimum_and_rejects_anything_else(monkeypatch):
+    """axt_mcf_solve_duals / axt_mcf_shard_finish_duals: the node potentials returned with the trajectories satisfy
+    complementary slackness over ALL arcs (helpers.check_flow_certificate: O(arcs), no second solve) -- in every regime of the
+    solver (assignment form with the flow count strictly inside its bounds; successive shortest paths with max_flow binding,
+    with min_flow binding, with no further path at all), for the two-phase and the one-phase schedule, threaded, and for the
+    solve shared between ranks. The checker has teeth: a worse flow, a flow with a detection on two tracks, wrong
+    potentials and a wrong total each fail it."""
+    from helpers import c3_network, moving_network, check_flow_certificate
+    monkeypatch.setenv('AXT_MCF_THREADS', '4')
+    c3 = c3_network()[:6]
+    small = moving_network(30, 256, 12, seed=2)[:6]
+    cases = [(c3, 5, 450), (c3, 5, 40), (c3, 80, 450), (small, 0, 1000), (small, 0, 3), (small, 40, 1000),
+             (moving_network(60, 512, 60, seed=5)[:6], 5, 100000)]
+    for net, lo, hi in cases:
+        res = hp.mcf_solve(*net, lo, hi, duals=True)
+        assert res is not None
+        plain = hp.mcf_solve(*net, lo, hi)
+        assert np.array_equal(res[0], plain[0]) and np.array_equal(res[1], plain[1]) and res[2:4] == plain[2:4]
+        out = check_flow_certificate(*net, res[0], res[1], res[3], res[4], lo, hi)
+        assert out['trajectories'] == res[2]
+    # every detection used up: no further path exists (the branch that shifts the reached part of the network)
+    tiny = moving_network(4, 128, 3, seed=1)[:6]
+    full = hp.mcf_solve(*tiny, len(tiny[0]), 10 ** 6, duals=True)
+    if full is not None:
+        check_flow_certificate(*tiny, full[0], full[1], full[3], full[4], len(tiny[0]), 10 ** 6)
+    # schedules and the forced successive-shortest-path solver
+    for env in ({'AXT_MCF_ONE_PHASE': '1'}, {'AXT_MCF_TWO_PHASE': '1'}, {'AXT_MCF_FORCE_SSP': '1'}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        net = small if 'AXT_MCF_FORCE_SSP' not in env else moving_network(20, 256, 10, seed=4)[:6]
+        res = hp.mcf_solve(*net, 0, 1000, duals=True)
+        check_flow_certificate(*net, res[0], res[1], res[3], res[4], 0, 1000)
+        for k in env:
+            monkeypatch.delenv(k)
+    # shared between ranks
+    net = moving_network(120, 512, 90, seed=3)[:6]
+    shards = [hp.McfShard(*net, r, 2) for r in range(2)]
+    states = [s.state for s in shards]
+    for s in shards:
+        res = s.finish(states, 5, 100000, duals=True)
+        check_flow_certificate(*net, res[0], res[1], res[3], res[4], 5, 100000)
+    # ---- the checker rejects what is not the optimum
+    net, lo, hi = c3, 5, 450
+    nxt, track, n_tracks, total, pots = hp.mcf_solve(*net, lo, hi, duals=True)
+    obs, en, ex, row_ptr, col, cost = net
+    # (1) a feasible but worse flow: one trajectory removed, total recomputed honestly
+    worse_track = np.where(track == n_tracks - 1, -1, track)
+    worse_next = np.where(track == n_tracks - 1, -1, nxt)
+    gone = track == n_tracks - 1
+    tail = np.repeat(np.arange(len(obs)), np.diff(row_ptr))
+    on = (nxt[tail] == col) & gone[tail]
+    first = gone & (np.bincount(nxt[nxt >= 0], minlength=len(obs)) == 0)
+    worse_total = total - int(obs[gone].sum() + cost[on].sum() + en[first].sum() + ex[gone & (nxt < 0)].sum())
+    with pytest.raises(AssertionError, match='reduced cost'):
+        check_flow_certificate(*net, worse_next, worse_track, worse_total, pots, lo, hi)
+    # (2) not a flow: a detection gets a second predecessor
+    k = int(np.flatnonzero(nxt >= 0)[0])
+    other = int(np.flatnonzero((nxt >= 0) & (np.arange(len(nxt)) != k) & (track != track[k]))[0])
+    bad_next = nxt.copy(); bad_next[other] = nxt[k]
+    with pytest.raises(AssertionError):
+        check_flow_certificate(*net, bad_next, track, total, pots, lo, hi)
+    # (3) potentials that are not the optimum's, (4) a wrong total
+    bad = (pots[0].copy(), pots[1].copy(), pots[2]); bad[1][k] += 1 << 30
+    with pytest.raises(AssertionError, match='reduced cost'):
+        check_flow_certificate(*net, nxt, track, total, bad, lo, hi)
+    with pytest.raises(AssertionError, match='total cost'):
+        check_flow_certificate(*net, nxt, track, total + 1, pots, lo, hi)
