@@ -8,7 +8,9 @@ One "step" = one pass of the hot path (axtrack_amd.inference: CNN forward -> dec
 [all-gather] -> association -> IDed_dets_all; the list of non-empty tiles belongs to the dataset, as in the
 reference, and is computed once when the timelapse is first used)
 over a synthetic 512x512 timelapse that is already resident in HBM. Default workload is BASELINE
-config "c3" (512x512x256, detection + association); "c2" is detection only.
+config "c3" (512x512x256, detection + association); "c2" is detection only; "c4" / "c5" are BASELINE configs 4 and 5
+(1024x1024 frames, the reference's global min-cost-flow tracker; c5 under the corridor mask with path costs on the masked
+grid): frame-sharded like c3, `--gpus 1` runs ONE GPU's share of the 8-GPU configuration (132 / 68 input frames).
 
 Multi-GPU (weak scaling): the timelapse has N x 252 detection frames, rank r detects its own
 contiguous block (reading a 2-frame halo), ONE all-gather of the detection lists over RCCL, then the
@@ -37,13 +39,42 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2516.6    # dense bf16 MFMA (16 x the f32 rate); the bf16x3 line prices a multiply-add at 6 products
 
 
+# BASELINE configs 4 and 5: (frame size, input frames of the whole configuration, GPUs it is stated for)
+BIG_CONFIGS = {'c4': (1024, 1024, 8), 'c5': (1024, 512, 8)}
+
+
+def resolve_workload(args):
+    """Fill in what the workload's name implies: frame size, input frames per GPU, association. c4 / c5 are stated for 8 GPUs:
+    a rank gets one eighth of the configuration's detection frames (rounded up) whatever --gpus is, so that --gpus 8 is the
+    configuration itself and --gpus 1 one GPU's share of it."""
+    wl = args.workload
+    if wl in BIG_CONFIGS:
+        size, t_all, gpus = BIG_CONFIGS[wl]
+        if args.size is None:
+            args.size = size
+        if args.frames is None:
+            args.frames = -(-(t_all - 4) // gpus) + 4
+        args.assoc = 'mcf'                      # the configurations name the global flow tracker
+        args.input = 'hbm'
+    else:
+        if args.size is None:
+            args.size = 512
+        if args.frames is None:
+            args.frames = 256
+    args.associates = wl in ('c3', 'c4', 'c5')
+    args.big = wl in BIG_CONFIGS
+    return args
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--workload', default='c3', choices=['c2', 'c3', 'assoc-c3', 'assoc-c4'],
-                    help="c3 (default, BASELINE config 3) / c2 (detection only); assoc-c3 / assoc-c4: ASSOCIATION ONLY on the detections of a "
+    ap.add_argument('--workload', default='c3', choices=['c2', 'c3', 'c4', 'c5', 'assoc-c3', 'assoc-c4'],
+                    help="c3 (default, BASELINE config 3) / c2 (detection only); c4 / c5: BASELINE configs 4 and 5 (1024x1024 frames, global "
+                         "min-cost flow; c5 with synth.corridor_mask and path costs on the masked grid), per GPU one eighth of the "
+                         "configuration's frames (--frames 132 / 68 unless given); assoc-c3 / assoc-c4: ASSOCIATION ONLY on the detections of a "
                          "scene of moving growth cones (births, deaths, misses, clutter; synth.synth_detections) at the size of config 3 / 4 -- "
                          "separate lines for the flow tracker, whose cost depends on the scene (the random-init detector gives a static one)")
     ap.add_argument('--assoc', default='hungarian', choices=['hungarian', 'mcf'],
@@ -60,8 +91,8 @@ def main():
                          "preprocessing and the CNN of the previous chunk (a SEPARATE line: the PCIe-inclusive rate)")
     ap.add_argument('--no-host-variant', action='store_true', help='skip the host-resident-input passes after the timed region')
     ap.add_argument('--chunk', type=int, default=96, help='largest chunk of input frames of --input host (the chunks grow from 16)')
-    ap.add_argument('--frames', type=int, default=256, help='input frames per GPU (T_all)')
-    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--frames', type=int, default=None, help='input frames per GPU (T_all): 256 (c2, c3), 132 (c4), 68 (c5)')
+    ap.add_argument('--size', type=int, default=None, help='frame height = width: 512 (c2, c3), 1024 (c4, c5)')
     ap.add_argument('--cpu-frames', type=int, default=252, help='detection frames of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--no-profile', action='store_true', help='do not bracket kernels with HIP events')
     ap.add_argument('--no-verify', action='store_true',
@@ -73,6 +104,7 @@ def main():
     ap.add_argument('--launch-check', action='store_true',
                     help='no GPU work: every rank joins a gloo group, one all-reduce, rank 0 prints what it saw (tests the launcher)')
     args = ap.parse_args()
+    resolve_workload(args)
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # a bare `python bench.py --gpus N`: this process becomes the launcher of N ranks (it never touches the GPU)
@@ -119,6 +151,10 @@ def main():
     # this rank's block of the global timelapse, with its 2-frame halo on both sides
     f0 = rank * per_rank
     frames = synth.synth_frames(T_all_global, H, W, seed=0, t_range=(f0, f0 + per_rank + 4))
+    mask = None
+    if args.workload == 'c5':                       # BASELINE config 5: occlusion mask, path costs on the masked grid
+        mask = synth.corridor_mask(H, W, width=40, pitch=128)
+        frames *= mask[None].astype(np.float32)
     frames_host = frames if (rank == 0 and not args.no_verify) else None     # the checker's copy (rank 0's block)
     sd = synth.synth_state_dict(42)
     P = params.load_parameters()
@@ -146,7 +182,7 @@ def main():
         if frames_host is not None:
             frames_host = tl.frames.cpu().numpy()          # the checker reads what the preprocessing produced
     else:
-        tl = axtrack_amd.Timelapse(frames, name='bench', device=dev)
+        tl = axtrack_amd.Timelapse(frames, name='bench', mask=mask, device=dev)
     del frames
     if world > 1:
         tl.sync_tile_occupancy()          # the kept-tile list is a property of the whole timelapse (Timelapse.py:551-558)
@@ -154,7 +190,7 @@ def main():
     def step():
         ad = axtrack_amd.AxonDetections(model, host_tl() if raw_pinned is not None else tl, P, None)
         ad.detect_dataset(cache=None)
-        if args.workload == 'c3':
+        if args.associates:
             if world > 1:
                 ad.gather_detections()
             ad.assign_ids(None, None)
@@ -208,7 +244,7 @@ def main():
     from axtrack_amd import sharded
     ad2 = axtrack_amd.AxonDetections(model, host_tl() if raw_pinned is not None else tl, P, None)
     timed('detect_ms', lambda: ad2.detect_dataset(cache=None))
-    if args.workload == 'c3':
+    if args.associates:
         sharded.COLLECTIVE_MS = {}                     # per-collective wall time of this (untimed, synchronised) step
         if world > 1:
             timed('allgather_ms', ad2.gather_detections)
@@ -218,7 +254,7 @@ def main():
 
     # every rank must hold the same association: compare a hash of the trajectory ids of the whole timelapse
     same_on_all_ranks = None
-    if args.workload == 'c3' and world > 1:
+    if args.associates and world > 1:
         import hashlib
         digest = hashlib.sha256(np.ascontiguousarray(ad._track_flat).tobytes()).digest()[:8]
         h = torch.tensor([int.from_bytes(digest, 'little', signed=True)], dtype=torch.int64, device=dev)
@@ -230,7 +266,7 @@ def main():
 
     # the direct-convolution f32 kernels on the same workload, measured in the same run (after the timed region)
     direct = None
-    if winograd and world == 1:
+    if winograd and world == 1 and not args.big:
         Pd = dict(P, CNN_ARITH='f32_direct')
         def step_direct():
             a = axtrack_amd.AxonDetections(model, tl, Pd, None)
@@ -250,7 +286,7 @@ def main():
 
     # the same pass from host-resident raw input, measured in the same run (after the timed region): the PCIe-inclusive rate
     host_variant = None
-    if args.input == 'hbm' and world == 1 and not args.no_host_variant:
+    if args.input == 'hbm' and world == 1 and not args.no_host_variant and not args.big:
         scale = params.DEPLOYED_STND_SCALER[1][0]
         fr = tl.frames.cpu().numpy()
         raw = np.clip((2.0 ** (fr.astype(np.float64) * scale) - 1.0) * 65535.0 + 121.0 * (fr > 0), 0, 65535).astype(np.uint16)
@@ -292,10 +328,42 @@ def main():
         other = {'association': P2['ASSOCIATION'], 'value': round(total_frames / dt3, 2), 'unit': 'frames/s',
                  'ms_per_step': round(dt3 * 1e3, 3), 'n_ids': ad3.n_ids, 'steps': 1}
 
+    # A real timelapse is processed once: the pass over a FRESH timelapse object of the same frames (the kept-tile list is
+    # computed again, the identity count that sizes IDed_dets_all is fetched instead of guessed from the previous pass),
+    # timed after the timed region for the steady_state note of the line
+    fresh_ms = None
+    if world == 1 and args.input == 'hbm':
+        from axtrack_amd import detections as _det
+        _det._IDS_GUESS.clear()
+        tl_fresh = axtrack_amd.Timelapse(tl.frames, name='bench', mask=mask, device=dev)
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        a = axtrack_amd.AxonDetections(model, tl_fresh, P, None)
+        a.detect_dataset(cache=None)
+        if args.associates:
+            a.assign_ids(None, None)
+        torch.cuda.synchronize(dev)
+        fresh_ms = round((time.perf_counter() - t) * 1e3, 3)
+        del a, tl_fresh
+
+    # the flow tracker's optimality certificate (axt_mcf_solve_duals): one more untimed step on every rank (the shared solve is
+    # collective), checked on rank 0 in verify()
+    cert = None
+    if args.associates and args.assoc == 'mcf' and not args.no_verify:
+        Pc = dict(P, MCF_CERTIFICATE=True)
+        ac = axtrack_amd.AxonDetections(model, tl, Pc, None)
+        ac.detect_dataset(cache=None)
+        if world > 1:
+            ac.gather_detections()
+        ac.assign_ids(None, None)
+        cert = ac.mcf_certificate
+        assert np.array_equal(ac._track_flat, ad._track_flat), 'the certified step found other trajectories than the timed one'
+        del ac
+
     if rank == 0:
         value = total_frames * args.steps / dt
         out = {
-            'metric': ('frames/sec end-to-end detect+associate, 512x512xT timelapse' if args.workload == 'c3'
+            'metric': (f'frames/sec end-to-end detect+associate, {H}x{W}xT timelapse' if args.associates
                        else 'frames/sec detection only (CNN forward + NMS), 512x512xT timelapse')
                       + (' -- raw uint16 input in host memory, H2D copy and preprocessing inside every pass (PCIe-inclusive)' if args.input == 'host' else ''),
             'value': round(value, 2), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -305,14 +373,23 @@ def main():
             'data': 'synthetic',
             'config': {'workload': f'{args.workload}: synthetic {H}x{W}x{args.frames} grayscale timelapse per GPU, '
                                    + (f'detection + path-cost matrix + {"Hungarian (frame-to-frame)" if args.assoc == "hungarian" else "global min-cost-flow"} association (IDed_dets_all)'
-                                      if args.workload == 'c3' else 'detection only'),
-                       'association': args.assoc if args.workload == 'c3' else None,
+                                      if args.associates else 'detection only')
+                                   + ('' if not args.big else
+                                      f'; BASELINE config {args.workload[1]} = {BIG_CONFIGS[args.workload][0]}x{BIG_CONFIGS[args.workload][0]}x{BIG_CONFIGS[args.workload][1]} on '
+                                      f'{BIG_CONFIGS[args.workload][2]} GPUs' + (', occlusion mask (40-px corridors on a 128-px lattice), path costs on the masked grid' if mask is not None else ', all-ones mask')
+                                      + f': this run is {world} of {BIG_CONFIGS[args.workload][2]} GPU shares ({per_rank} detection frames per GPU), the timelapse it solves has {total_frames} detection frames'),
+                       'association': args.assoc if args.associates else None,
                        'detection_frames_per_gpu': per_rank, 'tiles_per_frame': n_tiles,
                        'weights': 'random-init (synth seed 42)', 'parallelism': f'frame-sharded x{world}',
                        'input': 'hbm_resident' if args.input == 'hbm' else 'host_u16',
                        'input_detail': ('preprocessed f32 frames resident in HBM when the timed region starts' if args.input == 'hbm' else
                                         f'raw uint16 frames in pinned host memory: every pass copies them on a second stream (16-frame pieces) beside '
                                         f'axt_preprocess_u16 and the CNN of the frames already there (chunks of 16, 32, 48, 64, 80, then {args.chunk} frames; PCIe-inclusive)'),
+                       'steady_state': {'what': 'the timed passes run over ONE timelapse object: its kept-tile list (a property of the dataset, Timelapse.py:551-558) '
+                                                'is computed by the first pass and kept, and IDed_dets_all is sized from the identity count of the previous pass '
+                                                'over a timelapse of this shape instead of a device-to-host round trip; packed weights belong to the Detector',
+                                        'fresh_timelapse_pass_ms': fresh_ms,
+                                        'fresh_timelapse_pass': 'one pass over a new Timelapse object of the same frames with the identity-count guess cleared (after the timed region)'},
                        'cnn_arith': args.arith,
                        'conv_algorithm': ('Winograd F(2x2,3x3), f32, for the six stride-1 conv blocks (2,4,5,7,8,10); direct for the two stride-2 blocks'
                                           if winograd else 'direct') + ('; the two stride-2 blocks fused into one kernel' if getattr(model, 'fused_front', False) else '')},
@@ -322,12 +399,12 @@ def main():
         if world > 1:
             out['rccl_world'] = dist.get_world_size() if args.backend == 'nccl' else 0
             out['backend'] = args.backend
-            if args.workload == 'c3':
+            if args.associates:
                 out['collectives_ms'] = collectives
                 out['tracks_identical_on_all_ranks'] = same_on_all_ranks
         if not args.no_verify:
-            out.update(verify(args, ad, frames_host, sd, per_rank, world))
-        if args.workload == 'c3':
+            out.update(verify(args, ad, frames_host, sd, per_rank, world, mask, cert))
+        if args.associates:
             out['n_ids'] = getattr(ad, 'n_ids', None)
             if other:
                 out['other_association_variant'] = other
@@ -352,7 +429,7 @@ def main():
             out['roofline'] = {
                 'bound': 'mfma', 'kernel': dom['name'], 'achieved': round(achieved, 2), 'peak': round(peak, 1),
                 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
-                **committed_counters(table, dom['name'], winograd, wino_blocks, cnn_ms),
+                **committed_counters(table, dom['name'], winograd, wino_blocks, cnn_ms, args),
                 'avg_launch_ms': round(dom['ms'] / max(dom['launches'], 1), 4),
                 'flops_per_launch': flops / max(dom['launches'], 1),
                 'flops': ('executed on the matrix pipe (Winograd: 16/36 of the direct convolution\'s); '
@@ -494,28 +571,42 @@ def launch_ranks(n):
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    try:
+    # rank 0's stdout is passed through by a reader thread while ALL children are polled: a rank that dies leaves the others
+    # waiting in a collective (until the backend's timeout, tens of minutes), so the first failure ends the run at once
+    import threading
+    def pump():
         for line in procs[0].stdout:                    # rank 0 prints the one JSON line; library chatter goes to stderr
             out = sys.stdout if line.lstrip().startswith(b'{') else sys.stderr
             out.buffer.write(line)
             out.flush()
-        for r, p in enumerate(procs):
-            code = p.wait()
-            if code != 0:
-                print(f'bench.py: rank {r} exited with code {code}', file=sys.stderr)
-                rc = rc or (code if code > 0 else 1)
+    reader = threading.Thread(target=pump, daemon=True)
+    reader.start()
+    rc = 0
+    try:
+        alive = set(range(n))
+        while alive and rc == 0:
+            for r in sorted(alive):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                alive.discard(r)
+                if code != 0:
+                    print(f'bench.py: rank {r} exited with code {code}', file=sys.stderr)
+                    rc = code if code > 0 else 1
+                    break
+            if alive and rc == 0:
+                time.sleep(0.05)
     finally:
-        for p in procs:                                 # a rank that failed leaves the others waiting in a collective
+        for p in procs:
             if p.poll() is None:
-                if rc == 0:
-                    p.wait()
-                else:
-                    p.kill()
+                p.kill()
+        for p in procs:
+            p.wait()
+        reader.join(timeout=5)
     return rc
 
 
-def verify(args, ad, frames_host, sd, per_rank, world):
+def verify(args, ad, frames_host, sd, per_rank, world, mask=None, cert=None):
     """Self-check of the configuration that was just timed (same Detector, same launch shapes), outside the timed region,
     against the CPU oracle: YOLO grids of 8 frames sampled across every front-layer launch within 1e-5 of the oracle's
     f32 forward pass; the detection lists of ALL of rank 0's frames bit-exact given those grids; the trajectories equal
@@ -540,7 +631,50 @@ def verify(args, ad, frames_host, sd, per_rank, world):
         ok_det &= bool(cnt[t] == n and np.array_equal(conf[t, :n], rc) and np.array_equal(x[t, :n], rx)
                        and np.array_equal(y[t, :n], ry))
     ok_assoc, what = None, 'not checked'
-    if args.workload == 'c3' and world == 1:
+    extra = {}
+    if cert is not None:
+        # optimality of the flow tracker's trajectories: complementary slackness of its node potentials over all arcs
+        from tests.helpers import check_flow_certificate
+        try:
+            proof = check_flow_certificate(cert['obs'], cert['entry'], cert['exit'], cert['row_ptr'], cert['col'], cert['cost'], cert['next'],
+                                           cert['track'], cert['total_cost'], cert['potentials'], cert['min_flow'], cert['max_flow'])
+            extra['flow_certificate'] = dict(proof, ok=True, what='reduced cost >= 0 on every arc without flow, <= 0 on every arc with flow '
+                                                                  '(axt_mcf_solve_duals), flow feasible, total cost recomputed')
+        except AssertionError as e:
+            extra['flow_certificate'] = {'ok': False, 'why': str(e)}
+    if args.big:
+        # configs 4 / 5: the oracle's Bellman-Ford tracker does not finish at this size; the certificate above proves the
+        # optimum, and sampled rows of the network are compared with the oracle's path lengths, admission and integer costs
+        Pc = dict(orc.DEFAULTS)
+        offs = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+        det = lambda t: (conf[t, :cnt[t]], x[t, :cnt[t]].astype(np.int64), y[t, :cnt[t]].astype(np.int64))
+        rng = np.random.default_rng(5)
+        H, W = frames_host.shape[1:]
+        n_rows = n_arcs = 0
+        ok_arcs = cert is not None
+        if cert is not None:
+            row_ptr, col, cost = cert['row_ptr'], cert['col'], cert['cost']
+            for t in (0, F // 2):
+                pick = np.arange(cnt[t]) if mask is None else np.sort(rng.choice(cnt[t], min(4, cnt[t]), replace=False))
+                src = tuple(a[pick] for a in det(t))
+                want = {int(i): [] for i in pick}
+                for g in (1, 2):
+                    if t + g >= len(cnt):
+                        continue
+                    D = orc.path_matrix(src, det(t + g), H, W, mask)
+                    c = orc.transition_cost(D, g, Pc['MCF_MISS_RATE'])
+                    for r, j in zip(*np.nonzero(c < Pc['MCF_EDGE_COST_THR'])):
+                        a, b = int(offs[t] + pick[r]), int(offs[t + g] + j)
+                        want[int(pick[r])].append((b, orc.arc_cost_int(c[r, j], 3, a, b)))
+                for i in pick:
+                    a = int(offs[t] + i)
+                    got = sorted(zip(col[row_ptr[a]:row_ptr[a + 1]].tolist(), cost[row_ptr[a]:row_ptr[a + 1]].tolist()))
+                    ok_arcs &= got == sorted(want[int(i)])
+                    n_rows += 1; n_arcs += len(got)
+        extra['arc_rows_vs_oracle'] = {'rows': n_rows, 'arcs': n_arcs, 'ok': bool(ok_arcs)}
+        ok_assoc = bool(ok_arcs and extra.get('flow_certificate', {}).get('ok', False))
+        what = 'optimality certificate over all arcs + sampled arc rows equal to the oracle (the oracle tracker does not finish at this size)'
+    elif args.workload == 'c3' and world == 1:
         Pc = dict(orc.DEFAULTS)
         ref = orc.inference(frames_host, sd, P=Pc, yolo=list(yolo), assoc=args.assoc)
         frame_of = np.repeat(np.arange(len(cnt)), cnt)
@@ -555,11 +689,12 @@ def verify(args, ad, frames_host, sd, per_rank, world):
         what = f'trajectories equal to the oracle ({args.assoc})'
     elif args.workload == 'c3':
         what = 'cross-rank hash of the trajectories (tracks_identical_on_all_ranks)'
-    return {'verified': bool(ok_cnn and ok_det and ok_assoc is not False),
-            'verify': {'cnn_frames': sample, 'cnn_max_rel_err': float(f'{err:.3e}'), 'cnn_ok': ok_cnn,
-                       'detections_bit_exact_frames': len(ref_dets), 'detections_ok': ok_det,
-                       'association': what, 'association_ok': ok_assoc,
-                       'seconds': round(time.perf_counter() - t0, 1)}}
+    ok_cert = extra.get('flow_certificate', {}).get('ok', True)
+    return {'verified': bool(ok_cnn and ok_det and ok_assoc is not False and ok_cert),
+            'verify': dict({'cnn_frames': sample, 'cnn_max_rel_err': float(f'{err:.3e}'), 'cnn_ok': ok_cnn,
+                            'detections_bit_exact_frames': len(ref_dets), 'detections_ok': ok_det,
+                            'association': what, 'association_ok': ok_assoc}, **extra,
+                           seconds=round(time.perf_counter() - t0, 1))}
 
 
 def _profile_key(name):
@@ -582,7 +717,35 @@ def _read_profile_csv(path):
     return rows
 
 
-def committed_counters(table, dom_name, winograd, wino_blocks, ms_per_step_cnn):
+def _profile_set_matches(csv_path, args):
+    """(ok, reason): a committed rocprofv3 summary may feed this line only if it measured THESE kernel sources and THIS workload:
+    profiles/<tag>_meta.json (profiles/profile_meta.py, written by the collection scripts) holds the sha256 of the conv kernel
+    sources and the bench.py arguments of the profiled command."""
+    sys.path.insert(0, os.path.join(ROOT, 'profiles'))
+    import profile_meta
+    tag = os.path.basename(csv_path).rsplit('_', 1)[0]
+    for cand in (f'{tag}_pmc_meta.json' if csv_path.endswith('_pmc.csv') else f'{tag}_meta.json', f'{tag}_meta.json'):
+        path = os.path.join(ROOT, 'profiles', cand)
+        if os.path.exists(path):
+            break
+    else:
+        return False, f'{os.path.basename(csv_path)}: no {tag}_meta.json beside it (collected before round 4: sources and command unknown)'
+    meta = json.load(open(path))
+    if meta.get('sources_sha256') != profile_meta.sources_sha256(ROOT):
+        return False, f'{cand}: the conv kernel sources have changed since this set was collected'
+    mine = profile_meta.workload_key(['--workload', args.workload, '--assoc', args.assoc, '--arith', args.arith, '--input', args.input,
+                                      '--size', str(args.size), '--frames', str(args.frames)])
+    theirs = dict(meta.get('workload_key', {}))
+    for k in ('size', 'frames'):                      # defaults spelled out
+        if theirs.get(k) is None:
+            theirs[k] = {'size': {'c4': '1024', 'c5': '1024'}.get(theirs.get('workload'), '512'),
+                         'frames': {'c4': '132', 'c5': '68'}.get(theirs.get('workload'), '256')}[k]
+    if theirs != mine:
+        return False, f'{cand}: collected for {theirs}, this command is {mine}'
+    return True, cand
+
+
+def committed_counters(table, dom_name, winograd, wino_blocks, ms_per_step_cnn, args=None):
     """The north-star counters of this command from the committed rocprofv3 passes (profiles/, newest set that holds
     the dominant kernel): HBM bytes per launch and GB/s (FETCH_SIZE / WRITE_SIZE, separate --pmc passes, FETCH doubled per
     the gfx950 correction) and the matrix-pipe busy fraction (SQ_VALU_MFMA_BUSY_CYCLES over GRBM_GUI_ACTIVE / 8 XCDs x 1024
@@ -604,11 +767,16 @@ def committed_counters(table, dom_name, winograd, wino_blocks, ms_per_step_cnn):
     out = {'traffic': None, 'hbm_gbps': None, 'mfma_busy': None}
     kfiles = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_kernels.csv')))           # r01_* < r02* < r03*: the newest round last
     pfiles = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc.csv')))
+    why = []
     for f in reversed(kfiles):
         rows = _read_profile_csv(f)
         d = match(rows, dom_name)
         if d is None or 'FETCH_SIZE_KB_per_launch' not in d:
             continue
+        ok, reason = _profile_set_matches(f, args) if args is not None else (True, '')
+        if not ok:                                  # only the newest set that holds the kernel is a candidate: never fall back to an older one
+            why.append(reason)
+            break
         def nbytes(r):
             return (2 * float(r['FETCH_SIZE_KB_per_launch']) + float(r['WRITE_SIZE_KB_per_launch'])) * 1024
         out['traffic'] = int(nbytes(d))
@@ -630,6 +798,10 @@ def committed_counters(table, dom_name, winograd, wino_blocks, ms_per_step_cnn):
         d = match(rows, dom_name)
         if d is None:
             continue
+        ok, reason = _profile_set_matches(f, args) if args is not None else (True, '')
+        if not ok:
+            why.append(reason)
+            break
         busy = lambda r: float(r['SQ_VALU_MFMA_BUSY_CYCLES']) / (float(r['GRBM_GUI_ACTIVE']) / 8 * 1024)
         num = den = 0.0
         for k in table:
@@ -639,14 +811,58 @@ def committed_counters(table, dom_name, winograd, wino_blocks, ms_per_step_cnn):
                 den += float(r['GRBM_GUI_ACTIVE']) / 8 * 1024 * k['launches']
         out['mfma_busy'] = {'kernel': round(busy(d), 3), 'whole_cnn_convs': round(num / den, 3) if den else None,
                             'source': os.path.relpath(f, ROOT),
-                            'how': 'SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), rocprofv3 --pmc pass of this command'}
+                            'how': 'SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), rocprofv3 --pmc pass of this command '
+                                   '(same kernel sources, same workload arguments: checked against the set\'s meta file)'}
         break
+    if why:
+        out['counters_withheld'] = why             # null counters with the reason, rather than stale ones under a fresh timing
     return out
+
+
+def cpu_baseline_big(args, sd, synth):
+    """Configs 4 / 5: the oracle on a bounded sample. c4: detection + global flow tracker on the first 24 detection frames.
+    c5: detection on the first 8 detection frames, the masked path search of 16 sampled source detections (the oracle's search
+    takes ~0.5 s per source and gap: a whole frame pair would take minutes), extrapolated to a frame's detections; the flow
+    solve of the 8 frames on open-grid path lengths (its cost does not depend on where the lengths come from)."""
+    from oracle import oracle as orc
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    orc.set_threads(cores)
+    H = W = args.size
+    n = min(24 if args.workload == 'c4' else 8, args.frames - 4)
+    frames = synth.synth_frames(args.frames, H, W, seed=0, t_range=(0, n + 4))
+    Pc = dict(orc.DEFAULTS, MCF_MIN_FLOW=1)
+    t = time.perf_counter()
+    if args.workload == 'c4':
+        orc.inference(frames, sd, P=Pc, assoc='mcf')
+        dt = time.perf_counter() - t
+        return {'value': round(n / dt, 3), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+                'sample': f'first {n} detection frames of the same synthetic timelapse: detection + path lengths + global flow tracker ({dt:.1f} s of CPU work), '
+                          f'oracle/ (C + numpy restatement, OpenMP x{cores})'}
+    mask = synth.corridor_mask(H, W, width=40, pitch=128)
+    frames *= mask[None].astype(np.float32)
+    dets, yolo = orc.detect_dataset(frames, sd, return_yolo=True)
+    t_det = time.perf_counter() - t
+    t = time.perf_counter()
+    k = min(16, len(dets[0][0]))
+    src = tuple(a[:k] for a in dets[0])
+    for g in (1, 2):
+        orc.path_matrix(src, dets[g], H, W, mask)
+    t_path = (time.perf_counter() - t) / k
+    t = time.perf_counter()
+    orc.inference(frames, sd, P=Pc, yolo=yolo, assoc='mcf')                 # open-grid lengths: the solve's share only
+    t_solve = time.perf_counter() - t
+    per_frame = t_det / n + t_path * float(np.mean([len(d[0]) for d in dets])) + t_solve / n
+    return {'value': round(1.0 / per_frame, 4), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+            'sample': f'EXTRAPOLATED from a bounded sample: detection of the first {n} detection frames ({t_det:.1f} s), the masked path search of {k} source '
+                      f'detections against both following frames ({t_path * k:.1f} s; x {np.mean([len(d[0]) for d in dets]):.0f} detections per frame), the flow solve of '
+                      f'those frames ({t_solve:.1f} s); oracle/ (C + numpy restatement, OpenMP x{cores})'}
 
 
 def cpu_baseline(args, sd, synth):
     """The CPU oracle on the first `cpu_frames` detection frames of the same timelapse."""
     from oracle import oracle as orc
+    if args.big:
+        return cpu_baseline_big(args, sd, synth)
     n = min(args.cpu_frames, args.frames - 4)
     cores = min(len(os.sched_getaffinity(0)), 16)          # a one-GPU box's CPU share
     orc.set_threads(cores)                                 # (the environment variable is read too early to matter here)

@@ -4,6 +4,7 @@
 set -e
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 tag=$1
+python3 $R/profiles/profile_meta.py ${tag} --cpu-frames 0 --no-verify --no-host-variant
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_stats -o p --output-format csv -- python3 $R/bench.py --cpu-frames 0 --no-verify --no-host-variant --steps 5 --warmup 2 > $R/gpurun_out/${tag}_stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/${tag}_fetch -o p --output-format csv -- python3 $R/bench.py --cpu-frames 0 --no-verify --no-host-variant --steps 2 --warmup 1 > $R/gpurun_out/${tag}_fetch.log 2>&1

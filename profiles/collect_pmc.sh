@@ -4,6 +4,7 @@
 set -e
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 tag=$1; shift
+python3 $R/profiles/profile_meta.py ${tag}_pmc --cpu-frames 0 --no-verify --no-host-variant "$@"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT \
     -d $R/gpurun_out/${tag}_pmc -o p --output-format csv -- python3 $R/bench.py --cpu-frames 0 --no-verify --no-host-variant --steps 2 --warmup 1 "$@" > $R/gpurun_out/${tag}_pmc.log 2>&1

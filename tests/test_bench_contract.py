@@ -101,3 +101,72 @@ def test_round_3_line_carries_the_counters_and_the_input_kind():
         for a in ('mcf', 'hungarian'):
             q = json.load(open(os.path.join(ROOT, 'profiles', f'r03zz_bench_{w}_{a}.json')))
             assert q['verified'] is True and q['roofline']['bound'] == 'hbm' and q['config']['association'] == a
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_workloads_c4_and_c5_resolve_to_one_gpu_share_of_the_baseline_configurations():
+    """`--workload c4 | c5` (BASELINE configs 4 and 5 by name): 1024x1024 frames, the global flow tracker, per GPU one eighth of
+    the configuration's detection frames (132 / 68 input frames) whatever --gpus is; explicit --frames / --size win; the other
+    workloads keep their defaults."""
+    import argparse
+    b = _bench_module()
+    def resolve(**kw):
+        ns = argparse.Namespace(workload='c3', size=None, frames=None, assoc='hungarian', input='hbm')
+        ns.__dict__.update(kw)
+        return b.resolve_workload(ns)
+    a = resolve(workload='c4')
+    assert (a.size, a.frames, a.assoc, a.associates, a.big) == (1024, 132, 'mcf', True, True)
+    assert 8 * (a.frames - 4) >= 1020                                   # eight shares cover the configuration's 1 020 detection frames
+    a = resolve(workload='c5')
+    assert (a.size, a.frames, a.assoc, a.associates, a.big) == (1024, 68, 'mcf', True, True) and 8 * (a.frames - 4) >= 508
+    a = resolve(workload='c4', frames=36, size=512)
+    assert (a.size, a.frames) == (512, 36)
+    a = resolve(workload='c3')
+    assert (a.size, a.frames, a.assoc, a.associates, a.big) == (512, 256, 'hungarian', True, False)
+    a = resolve(workload='c2')
+    assert (a.size, a.frames, a.associates, a.big) == (512, 256, False, False)
+
+
+def test_committed_counters_are_withheld_when_sources_or_command_differ(tmp_path, monkeypatch):
+    """roofline.traffic / hbm_gbps / mfma_busy come from committed rocprofv3 summaries: only from a set whose meta file says it
+    measured the present conv kernel sources and the present workload arguments -- otherwise null with the reason."""
+    import argparse, shutil, sys
+    b = _bench_module()
+    sys.path.insert(0, os.path.join(ROOT, 'profiles'))
+    import profile_meta
+    root = tmp_path / 'repo'
+    (root / 'profiles').mkdir(parents=True)
+    (root / 'axtrack_amd' / 'csrc').mkdir(parents=True)
+    for f in profile_meta.KERNEL_SOURCES:
+        shutil.copy(os.path.join(ROOT, f), root / f)
+    shutil.copy(os.path.join(ROOT, 'profiles', 'r03zz_kernels.csv'), root / 'profiles' / 't_kernels.csv')
+    shutil.copy(os.path.join(ROOT, 'profiles', 'r03zz_pmc.csv'), root / 'profiles' / 't_pmc.csv')
+    monkeypatch.setattr(b, 'ROOT', str(root))
+    args = argparse.Namespace(workload='c3', assoc='hungarian', arith='f32', input='hbm', size=512, frames=256)
+    table = [{'name': 'conv2 40>80 +pool', 'launches': 2, 'ms': 1.0}]
+    wino = ('conv2', 'conv4', 'conv5', 'conv7', 'conv8', 'conv10')
+    # no meta file: withheld
+    got = b.committed_counters(table, 'conv2 40>80 +pool', True, wino, 4.0, args)
+    assert got['traffic'] is None and got['mfma_busy'] is None and 'no t_meta.json' in got['counters_withheld'][0]
+    def meta(tag, argv, sha=None):
+        json.dump({'sources_sha256': sha or profile_meta.sources_sha256(str(root)), 'workload_key': profile_meta.workload_key(argv)},
+                  open(root / 'profiles' / f'{tag}_meta.json', 'w'))
+    meta('t', ['--cpu-frames', '0']); meta('t_pmc', ['--cpu-frames', '0'])
+    got = b.committed_counters(table, 'conv2 40>80 +pool', True, wino, 4.0, args)
+    assert got['traffic'] > 0 and 0.3 < got['mfma_busy']['kernel'] < 1 and 'counters_withheld' not in got
+    # another command line: withheld
+    other = argparse.Namespace(**dict(args.__dict__, assoc='mcf'))
+    got = b.committed_counters(table, 'conv2 40>80 +pool', True, wino, 4.0, other)
+    assert got['traffic'] is None and got['mfma_busy'] is None and 'collected for' in got['counters_withheld'][0]
+    # the kernel sources moved on: withheld
+    with open(root / profile_meta.KERNEL_SOURCES[0], 'a') as f:
+        f.write('\n// edited\n')
+    got = b.committed_counters(table, 'conv2 40>80 +pool', True, wino, 4.0, args)
+    assert got['traffic'] is None and 'sources have changed' in got['counters_withheld'][0]

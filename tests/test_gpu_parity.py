@@ -1870,6 +1870,36 @@ def test_bare_multi_gpu_bench_invocation_runs_two_ranks_on_this_gpu():
     assert b['config']['detection_frames_per_gpu'] == 32
 
 
+@pytest.mark.parametrize('wl', ['c4', 'c5'])
+def test_bench_workloads_c4_and_c5_one_share_and_two_ranks_on_this_gpu(wl):
+    """`python bench.py --workload c4 | c5` (BASELINE configs 4 and 5 by name), shortened to a few frames: one GPU's share
+    as a line with `roofline`, `cpu_baseline` and `verified` (sampled CNN frames, all detection lists, sampled arc rows against
+    the oracle, the flow certificate over all arcs), and the two-rank frame-sharded form rehearsed on this card over gloo
+    (detection all-gather, arcs, shared flow solve: every rank ends with the same trajectories, certificate on rank 0)."""
+    import json, subprocess, sys
+    root = os.path.join(os.path.dirname(__file__), '..')
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['AXT_MCF_MIN_LEAF'] = '256'                      # small time blocks, so that the shared solve has leaves to share
+    def run(*argv):
+        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--workload', wl, '--steps', '1', '--warmup', '1', *argv],
+                           env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1
+        return json.loads(lines[0])
+    b = run('--frames', '16')
+    assert b['verified'] is True and b['n_gpus'] == 1 and b['config']['tiles_per_frame'] == 4 and b['config']['association'] == 'mcf'
+    assert f'BASELINE config {wl[1]}' in b['config']['workload'] and '1024x1024' in b['metric']
+    v = b['verify']
+    assert v['flow_certificate']['ok'] is True and v['arc_rows_vs_oracle']['ok'] is True and v['arc_rows_vs_oracle']['arcs'] > 20
+    assert v['detections_bit_exact_frames'] == 12 and v['cnn_max_rel_err'] < 1e-5
+    assert b['roofline']['bound'] == 'mfma' and 0 < b['roofline']['frac'] < 1
+    assert b['cpu_baseline']['kind'] == 'port' and b['cpu_baseline']['value'] > 0 and b['config']['steady_state']['fresh_timelapse_pass_ms'] > 0
+    b2 = run('--gpus', '2', '--backend', 'gloo', '--single-device', '--frames', '12', '--cpu-frames', '0')
+    assert b2['n_gpus'] == 2 and b2['tracks_identical_on_all_ranks'] is True and b2['verified'] is True
+    assert b2['verify']['flow_certificate']['ok'] is True and b2['config']['detection_frames_per_gpu'] == 8
+
+
 def test_host_resident_input_streams_to_the_same_detections(weights):
     """Timelapse.from_host_u16: raw uint16 frames in (pinned) host memory, copied in chunks on a second stream beside the
     preprocessing and the CNN of the previous chunk (the reference's inference() starts from a host Timelapse,
