@@ -593,7 +593,10 @@ struct Lsap {
         int kMinLeaf = 1024;
         if (const char *e = getenv("AXT_MCF_MIN_LEAF")) kMinLeaf = atoi(e) >= 1 ? atoi(e) : 1;    // tests: force the tree on small networks
         leaves = 1;
-        while (leaves * 2 <= budget * world && n / (leaves * 2) >= kMinLeaf) leaves *= 2;
+        // shared between ranks: every rank must build the SAME tree, so nothing of this process (its CPU set, its environment's
+        // thread count) may enter the leaf count -- a fixed 16 leaves per rank, the thread budget of a one-GPU share
+        const int cap_leaves = world > 1 ? 16 * world : budget;
+        while (leaves * 2 <= cap_leaves && n / (leaves * 2) >= kMinLeaf) leaves *= 2;
         for (; leaves > 1; leaves /= 2) {
             cut_p.assign(leaves + 1, 0);
             cut_q.assign(leaves + 1, 0);
@@ -626,13 +629,33 @@ struct Lsap {
     // ---- state of a subtree of leaves [a, b): its rows [cut_q[a], cut_p[b]) and the columns they can reach, in-slots
     // [cut_q[a], cut_q[b]) and the rows' private exits. Layout: rows {u i64, col i32, arc i32}, in-slots {v i64, row i32, pad},
     // exits {v i64, row i32, pad}.
+    // (a 16-byte header first: a hash of the cuts of the whole tree, n and the leaf count -- a rank whose tree differs, e.g.
+    // through a different AXT_MCF_MIN_LEAF, is told so instead of importing a state laid out for other cuts)
+    uint64_t tree_hash() const
+    {
+        uint64_t h = 1469598103934665603ull;
+        auto mix = [&](uint64_t v) { h ^= v; h *= 1099511628211ull; };
+        mix((uint64_t)n); mix((uint64_t)leaves);
+        for (int32_t v : cut_p) mix((uint64_t)(uint32_t)v);
+        for (int32_t v : cut_q) mix((uint64_t)(uint32_t)v);
+        return h;
+    }
     int64_t state_bytes(int a, int b) const
     {
         const int64_t rows = cut_p[b] - cut_q[a], cols = cut_q[b] - cut_q[a];
-        return 16 * (rows + cols + rows);
+        return 16 + 16 * (rows + cols + rows);
+    }
+    bool state_matches(const unsigned char *in) const
+    {
+        struct Head { uint64_t h; int32_t n, leaves; };
+        const Head *hd = reinterpret_cast<const Head *>(in);
+        return hd->h == tree_hash() && hd->n == n && hd->leaves == leaves;
     }
     void export_state(int a, int b, unsigned char *out) const
     {
+        struct Head { uint64_t h; int32_t n, leaves; };
+        *reinterpret_cast<Head *>(out) = Head{tree_hash(), n, leaves};
+        out += 16;
         struct Rec { int64_t x; int32_t y, z; };
         Rec *o = reinterpret_cast<Rec *>(out);
         for (int k = cut_q[a]; k < cut_p[b]; ++k) *o++ = Rec{rw[k].u, rw[k].col, rw[k].arc};
@@ -641,6 +664,7 @@ struct Lsap {
     }
     void import_state(int a, int b, const unsigned char *in)
     {
+        in += 16;
         struct Rec { int64_t x; int32_t y, z; };
         const Rec *o = reinterpret_cast<const Rec *>(in);
         for (int k = cut_q[a]; k < cut_p[b]; ++k, ++o) { rw[k].u = o->x; rw[k].col = o->y; rw[k].arc = o->z; }
@@ -916,6 +940,10 @@ static int shard_finish_impl(axt_mcf_shard *sh, const void *const *h_states, con
                 if (r == sh->rank) continue;
                 if (!h_states || !h_states[r] || !h_state_bytes || h_state_bytes[r] != a.state_bytes(r * sh->group, (r + 1) * sh->group)) {
                     axt_set_error("axt_mcf_shard_finish: the state of rank %d is missing or has the wrong size", r);
+                    return AXT_EINVAL;
+                }
+                if (!a.state_matches(static_cast<const unsigned char *>(h_states[r]))) {
+                    axt_set_error("axt_mcf_shard_finish: rank %d built another time-block tree (different AXT_MCF_MIN_LEAF?): its state does not fit", r);
                     return AXT_EINVAL;
                 }
                 a.import_state(r * sh->group, (r + 1) * sh->group, static_cast<const unsigned char *>(h_states[r]));

@@ -659,6 +659,8 @@ class AxonDetections(object):
         """feature_model's histograms of every detection (device tensors hist f32 [F,cap,180], sums f64 [F,cap]),
         computed once from the centre frames (AxonDetections.py:682-685)."""
         if getattr(self, '_hist', None) is None:
+            if hasattr(self.dataset, 'make_resident'):
+                self.dataset.make_resident()            # (a host-resident timelapse that has not been streamed yet)
             frames, off = self.dataset.frames, 2
             if not isinstance(self.timepoint_subset, range) and getattr(self, '_shard', None) is None:
                 # the centre frames of the subset. (The reference hands the tracker get_frame_and_truedets(i) with i the POSITION in

@@ -81,6 +81,7 @@ class Timelapse:
         import os
         import pickle
         os.makedirs(directory, exist_ok=True)
+        self.make_resident()
         d = dict(_axtrack_amd_cache=1, name=self.name, frames=self.frames.cpu().numpy(),
                  mask=self.mask3d if self.mask3d is not None else self.mask2d, temporal_context=self.temporal_context,
                  tilesize=self.tilesize, pixelsize=self.pixelsize, dt=self.dt, incubation_time=self.incubation_time)
@@ -198,6 +199,15 @@ class Timelapse:
         self._pending = False
         self._host_raw = None
 
+    def make_resident(self):
+        """A host-resident timelapse (from_host_u16) holds an UNINITIALISED frame buffer until its chunks have been streamed:
+        everything that reads `frames` other than detect_dataset's own streaming loop (the tile list, the dataset cache, the
+        appearance histograms, the occupancy all-reduce) calls this first. A no-op for a resident timelapse."""
+        if getattr(self, '_pending', False):
+            for _ in self.stream_chunks():
+                pass
+        return self
+
     @property
     def tile_yx(self):
         """Row-major list of the (tile_row, tile_col) that hold a non-zero pixel at some time point: the reference's
@@ -205,6 +215,7 @@ class Timelapse:
         inference(). Computed on the GPU (axt_tile_occupancy) on first use and kept with the timelapse."""
         if getattr(self, '_tile_yx', None) is None:
             from . import hotpath as hp
+            self.make_resident()
             self._tile_yx = hp.tile_occupancy(self.frames)
         return self._tile_yx
 
@@ -215,6 +226,7 @@ class Timelapse:
         n_tiles, hence the same detection capacity, which the all-gather of the detections relies on."""
         import torch.distributed as dist
         from . import hotpath as hp
+        self.make_resident()
         occ = hp.tile_occupancy_bytes(self.frames)
         if dist.is_initialized() and dist.get_world_size(group) > 1:
             if dist.get_backend(group) == 'gloo':

@@ -1955,3 +1955,113 @@ def test_bench_lines_of_the_other_workloads_run_and_verify():
         a = run('--workload', 'assoc-c3', '--assoc', assoc, '--steps', '2', '--warmup', '1')
         assert a['verified'] is True and a['config']['input'] == 'detections_hbm_resident' and a['roofline']['bound'] == 'hbm'
         assert a['n_ids'] > 20 and a['value'] > 0 and a['unit'] == 'frames/s'
+
+
+def test_the_references_example_sequence_with_only_the_import_changed(tmp_path, monkeypatch, weights):
+    """examples/test.py of the reference (lines 1-44), call for call and in its argument spelling, against `import axtrack_amd as
+    axtrack` on synthetic files: PKG_DIR, setup_inference(dest_dir) finding the checkpoint in {PKG_DIR}/deployed_model,
+    parameters.update, prepare_input_data(..., mask_fname=<file>, use_cached_datasets='to', check_preproc=True, input_metadata with the
+    example's keys), inference(..., the three caches 'to'), IDed_dets_all, visualize_inference (out of scope: one clear error),
+    and the re-exported _compute_astar_path. Results against the oracle fed the same files."""
+    import pickle
+    import torch
+    import pandas as pd
+    import axtrack_amd as axtrack
+    from axtrack_amd import interface
+    # the package directory of the example: examples/ with the two input files, deployed_model/ with the checkpoint
+    pkg = tmp_path / 'pkg'
+    (pkg / 'examples').mkdir(parents=True)
+    (pkg / 'deployed_model').mkdir()
+    torch.save({'state_dict': {k: torch.from_numpy(np.asarray(v)) for k, v in weights.items()}}, pkg / 'deployed_model' / 'E1000.pth')
+    with open(pkg / 'deployed_model' / 'train_stnd_scaler.pkl', 'wb') as f:
+        pickle.dump(('zscore', (0.015176106, 0.009456525)), f)
+    monkeypatch.setattr(axtrack, 'PKG_DIR', str(pkg) + '/')
+    monkeypatch.setattr(interface, 'DEPLOYED_MODEL_DIR', str(pkg) + '/deployed_model/')
+    monkeypatch.delenv('AXTRACK_MODEL_DIR', raising=False)
+    scale = params.DEPLOYED_STND_SCALER[1][0]
+    f0 = synth.synth_frames(20, 512, 512, seed=7)
+    raw = np.clip((2.0 ** (f0 * scale) - 1.0) * 65535.0 + 121.0 * (f0 > 0), 0, 65535).astype(np.uint16)
+    mask = np.ones((512, 512), bool)                  # (a mask file as in the example; all ones, so that the oracle's tracker below runs
+                                                      #  on closed-form path lengths; masked grids end to end: the tests above)
+    np.save(pkg / 'examples' / 'example_timelapse.npy', raw)      # (.tif needs tifffile, which is absent: the array file instead)
+    np.save(pkg / 'examples' / 'example_timelapse_mask.npy', mask)
+
+    # ---- the example, from here on in its own words
+    inference_data_dir = f'{axtrack.PKG_DIR}/examples/'
+    dest_dir = inference_data_dir
+    imseq_fname = 'example_timelapse.npy'
+    mask_fname = 'example_timelapse_mask.npy'
+    parameters, model, stnd_scaler = axtrack.setup_inference(dest_dir)
+    parameters.update({'MCF_MAX_FLOW': 140})
+    use_cached_datasets = 'to'
+    check_preproc = True
+    input_metadata = {'dt': 31, 'pixelsize': .62, 'intensity_offset': 121,
+                      'clip_intensity': 55, 'incubation_time': 52,
+                      'name': 'example_timelapse'}
+    with pytest.warns(UserWarning, match='comparison plot'):
+        timelapse = axtrack.prepare_input_data(imseq_fname, parameters, dest_dir, inference_data_dir,
+                                               stnd_scaler, mask_fname=mask_fname, use_cached_datasets=use_cached_datasets,
+                                               check_preproc=check_preproc, input_metadata=input_metadata)
+    cache_detections = 'to'
+    astar_paths_cache = 'to'
+    assigedIDs_cache = 'to'
+    axon_dets = axtrack.inference(timelapse, model, dest_dir, parameters,
+                                  detections_cache=cache_detections,
+                                  astar_paths_cache=astar_paths_cache,
+                                  assigedIDs_cache=assigedIDs_cache)
+    dets = axon_dets.IDed_dets_all
+    print(dets)
+    with pytest.raises(NotImplementedError, match='out of scope'):
+        axtrack.visualize_inference(axon_dets, which_dets='IDed', draw_scalebar=False,
+                                    animated=True, show=False, draw_brightened_bg=True)
+
+    # ---- what it produced
+    assert stnd_scaler == ('zscore', (0.015176106, 0.009456525)) and parameters['MCF_MAX_FLOW'] == 140
+    stats = pd.read_csv(pkg / 'examples' / 'example_timelapse_preproc_data.csv', index_col=0, header=[0, 1, 2])
+    steps = [c[1] for c in stats.columns[::2]]
+    assert steps == ['Original', 'Clipped', 'Log-Adjusted', 'Standardized (frame-wize: False)'] and stats.shape == (1000000, 8)
+    assert [c[2] for c in stats.columns[:2]] == ['t_0', 't_-1'] and stats.columns[0][0] == 'example_timelapse'
+    fr = axon_dets.dataset.frames.cpu().numpy()
+    assert abs(stats.iloc[:, 6].max() - fr[2].max()) < 1e-6 or stats.iloc[:, 6].max() <= fr[2].max()      # samples of the standardized first time point
+    assert (stats.iloc[:, 0] >= stats.iloc[:, 2]).all()                     # clipping only removes
+    for f in ('example_timelapse_dataset_cached.pkl', 'axon_dets/example_timelapse__detections.pkl',
+              'axon_dets/example_timelapse_astar_dets_paths.pkl', 'axon_dets/example_timelapse__IDed_detections.pkl'):
+        assert (pkg / 'examples' / f).exists(), f
+    ref_frames = orc.preprocess(raw, mask, offset=121 / 2 ** 16, clip_lower=55 / 2 ** 16, log_correct=True, scale=scale)
+    np.testing.assert_array_max_ulp(fr, ref_frames, maxulp=2)
+    ref = orc.inference(fr, weights, mask=None, P=dict(orc.DEFAULTS, MCF_MAX_FLOW=140), name='example_timelapse',
+                        yolo=list(axon_dets._yolo.cpu().numpy()))
+    assert tracks_from_next(np.zeros(len(axon_dets._track_flat)), axon_dets._track_flat, axon_dets._offs) == ref['trajs']
+    assert axon_dets.mcf_total_cost == ref['total_cost']
+    ids, labels, info, vals = ref['ided_all']
+    assert list(dets.index) == [f'Axon_{i:0>3}' for i in ids]
+    assert np.array_equal(np.nan_to_num(dets.to_numpy(), nan=-1), np.nan_to_num(vals, nan=-1))
+
+    # ---- _compute_astar_path (reference __init__.py:16, utils.py:351-390) on the example's mask weights
+    mask = mask.copy()
+    mask[:, 250:262] = False                          # two regions
+    w = np.where(mask, 1, 2 ** 16).astype(np.float32)
+    cnt, conf, x, y = axon_dets._host_dets()
+    pairs = [((int(y[0, i]), int(x[0, i])), (int(y[1, j]), int(x[1, j]))) for i, j in ((0, 0), (1, 5), (3, 2), (7, 7))]
+    pairs.append(((100, 200), (100, 300)))            # across the gap in the mask
+    for src, dst in pairs:
+        if not (0 <= src[0] < 512 and 0 <= src[1] < 512 and 0 <= dst[0] < 512 and 0 <= dst[1] < 512):
+            continue
+        path, length = axtrack._compute_astar_path(src, dst, w, max_path_length=500)
+        D = orc.path_matrix((None, np.array([src[1]]), np.array([src[0]])), (None, np.array([dst[1]]), np.array([dst[0]])), 512, 512, mask, 500)
+        eu = np.hypot(src[0] - dst[0], src[1] - dst[1])
+        if D[0, 0] >= 500:
+            assert path is None and length is None or eu >= 500
+            continue
+        assert length == D[0, 0] == path.getnnz() and path.shape == (512, 512) and path.dtype == bool
+        cells = set(zip(path.row.tolist(), path.col.tolist()))
+        assert src in cells and dst in cells
+        # a 4-connected walk: every cell but the two ends has two neighbours on the path
+        nb = lambda c: sum(((c[0] + dy, c[1] + dx) in cells) for dy, dx in ((1, 0), (-1, 0), (0, 1), (0, -1)))
+        assert nb(src) >= 1 and nb(dst) >= 1 and all(nb(c) >= 2 for c in cells - {src, dst})
+    assert axtrack._compute_astar_path((5, 5), (5, 400), w, max_path_length=100) == (None, None)
+    assert axtrack._compute_astar_path((5, 5), (5, 400), w, return_dist=False, max_path_length=100) is None
+    p, n = axtrack._compute_astar_path((5, 5), (9, 2), np.ones((16, 16), np.float32))
+    assert n == 8 and p.getnnz() == 8
+    with pytest.raises(ValueError, match='mask weights'):
+        axtrack._compute_astar_path((5, 5), (9, 2), np.full((16, 16), 3.0, np.float32))

@@ -502,3 +502,33 @@ def test_flow_certificate_proves_the_optimum_and_rejects_anything_else(monkeypat
         check_flow_certificate(*net, nxt, track, total, bad, lo, hi)
     with pytest.raises(AssertionError, match='total cost'):
         check_flow_certificate(*net, nxt, track, total + 1, pots, lo, hi)
+
+
+def test_shared_flow_solve_does_not_depend_on_a_ranks_thread_count_and_rejects_another_tree(monkeypatch):
+    """The ranks of a shared solve must cut the timelapse into the same time blocks. The leaf count comes from rank-independent
+    inputs only (a rank's thread budget -- its CPU set, AXT_MCF_THREADS -- no longer enters), and a state carries a hash of
+    the cuts: a rank that built another tree (here: another AXT_MCF_MIN_LEAF) is refused instead of being imported."""
+    from helpers import moving_network
+    net = moving_network(120, 512, 90, seed=3)[:6]
+    ref = hp.mcf_solve(*net, 5, 100000)
+    monkeypatch.setenv('AXT_MCF_MIN_LEAF', '256')
+    monkeypatch.setenv('AXT_MCF_THREADS', '1')
+    s0 = hp.McfShard(*net, 0, 2)
+    monkeypatch.setenv('AXT_MCF_THREADS', '7')
+    s1 = hp.McfShard(*net, 1, 2)
+    assert len(s0.state) > 16 and len(s1.state) > 16
+    for s in (s0, s1):
+        got = s.finish([s0.state, s1.state], 5, 100000)
+        assert got[2] == ref[2] and got[3] == ref[3] and np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    monkeypatch.setenv('AXT_MCF_MIN_LEAF', '700')
+    other = hp.McfShard(*net, 1, 2)
+    s0b = hp.McfShard(*net, 0, 2)
+    monkeypatch.setenv('AXT_MCF_MIN_LEAF', '256')
+    s0c = hp.McfShard(*net, 0, 2)
+    if len(other.state) == len(s1.state):                 # same size by chance: only the hash can tell
+        with pytest.raises(_lib.AxtError, match='another time-block tree'):
+            s0c.finish([s0c.state, other.state], 5, 100000)
+    else:
+        with pytest.raises(_lib.AxtError):
+            s0c.finish([s0c.state, other.state], 5, 100000)
+    del s0b
