@@ -31,6 +31,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <memory>
 #include <mutex>
 #include <queue>
@@ -231,6 +233,76 @@ struct Lsap {
     std::unique_ptr<std::atomic<int32_t>[]> owner;        // per column: 0 = free, else the ticket of the holder
     std::atomic<uint32_t> next_stamp{0};
 
+    // ---- one search on several threads (Search::finish_in_parallel) ---------------------------------------------------------
+    // A handful of searches settle most of the network (config 4: one row of the root separator scans 244 k of the 319 k rows,
+    // 97 searches hold 84 % of the rows scanned on the critical path), and they sit on the spine of the time-block tree, where
+    // one thread works and the others have nothing left to do. A search that has grown past kParSwitch rows therefore goes on
+    // as a label-correcting search in buckets of distance ("near-far") on a team of threads: the labels the serial phase has
+    // settled stay, the open ones seed the first buckets, columns take (distance, predecessor row) in ONE 64-bit word by
+    // atomic minimum, and the nearest free column is an atomic minimum too. It ends with exactly the distances Dijkstra
+    // would have found for every column nearer than that free column -- which is all the dual update needs -- so the
+    // result is the serial one, at any team size.
+    static constexpr int kDistShift = 24;                 // label = distance << 24 | predecessor row (or column, for the bound)
+    static constexpr uint64_t kNoLabel = ~0ull;
+    std::unique_ptr<std::atomic<uint64_t>[]> plabel;      // per column, kNoLabel outside a parallel search
+    std::unique_ptr<int64_t[]> pexpanded;                 // per column: the distance its row was last expanded with (INF = never)
+    std::once_flag par_alloc;
+    int par_switch = 8192, par_buckets = 48;
+    struct HelperPool {
+        std::mutex m;
+        std::condition_variable cv;
+        std::vector<std::thread> threads;
+        struct Job { void *search; int tid; int epoch; };
+        std::deque<Job> jobs;
+        int idle = 0;
+        bool quit = false;
+    } pool;
+    std::atomic<int> tasks_running{0};                   // tree tasks (leaves, separators, the second phase) at work right now
+    void start_helpers()
+    {
+        if (!pool.threads.empty() || budget <= 1) return;
+        if (getenv("AXT_MCF_NO_PAR_SEARCH")) return;
+        if (const char *e = getenv("AXT_MCF_PAR_SWITCH")) par_switch = atoi(e) > 8 ? atoi(e) : 8;
+        if (const char *e = getenv("AXT_MCF_PAR_BUCKETS")) par_buckets = atoi(e) > 1 ? atoi(e) : 1;
+        if ((int64_t)n >= (1 << 23)) return;                 // predecessor rows and columns must fit the label's low bits
+        // Measured on the GPU box's host (16 threads, profiles/r04d_par_search.log): config 4 (319 k detections) 1 191 -> 725 ms of
+        // insertions, the root separator 484 -> 202 ms; config 3 (19 k) 18.7 -> 21-26 ms: its largest search is 14 k rows and a
+        // team costs more than it saves there. So: only networks of config 4's scale.
+        int min_n = 100000;
+        if (const char *e = getenv("AXT_MCF_PAR_MIN_N")) min_n = atoi(e);
+        if (n < min_n) return;
+        for (int t = 0; t < budget - 1; ++t) {
+            try { pool.threads.emplace_back([this] { helper_main(); }); } catch (...) { break; }
+        }
+    }
+    void stop_helpers()
+    {
+        {
+            std::lock_guard<std::mutex> g(pool.m);
+            pool.quit = true;
+        }
+        pool.cv.notify_all();
+        for (std::thread &t : pool.threads) t.join();
+        pool.threads.clear();
+        pool.quit = false;
+    }
+    void helper_main();
+    // up to `want` idle helpers for one search; they run Search::team_member(tid), tid = 1 .. returned count
+    int recruit(void *search, int want, int epoch)
+    {
+        if (pool.threads.empty() || want <= 0) return 0;
+        std::lock_guard<std::mutex> g(pool.m);
+        // threads that are busy with tree tasks count against the budget: a search only takes what would otherwise idle
+        const int spare = budget - tasks_running.load(std::memory_order_relaxed) - ((int)pool.threads.size() - pool.idle);
+        int k = std::min(std::min(want, pool.idle), spare);
+        if (k <= 0) return 0;
+        for (int t = 1; t <= k; ++t) pool.jobs.push_back(HelperPool::Job{search, t, epoch});
+        pool.idle -= k;
+        pool.cv.notify_all();
+        return k;
+    }
+    ~Lsap() { stop_helpers(); }
+
     typedef std::pair<int64_t, int32_t> Item;
     // One thread's search state. Several of them work on the shared rows / columns at the same time, on index ranges
     // that cannot meet (see run()).
@@ -339,7 +411,19 @@ struct Lsap {
         int cur = i, sink = -1;           // can be part of the shortest augmenting path, so it is not even queued
         sr_rows.clear();
         sc_cols.clear();
+        in_team = false;
+        par_next_try = (size_t)L.par_switch;
         while (sink < 0) {
+            if (!par && sr_rows.size() >= par_next_try && !sc_cols.empty() && best_free - c[sc_cols[0]].spc < ((int64_t)1 << 39)) {
+                // this search has grown large: the rest of it on whatever threads are idle (Lsap: "one search on several threads")
+                const int helpers = L.recruit(this, L.budget - 1, team.epoch.load(std::memory_order_relaxed) + 1);
+                if (helpers > 0) {
+                    sink = finish_in_parallel(i, helpers, minVal, best_free, open);
+                    in_team = true;
+                    break;
+                }
+                par_next_try = sr_rows.size() * 2;
+            }
             sr_rows.push_back(cur);
             const Row &rc = rw[cur];
             const int64_t off = minVal - rc.u;
@@ -433,12 +517,350 @@ struct Lsap {
             for (int k = 0; k < rr.degree; ++k) see(ap[k].head, rr.base + ap[k].w);
             if (all && best2 < INF && best2 > rr.u) { rr.u = best2; c[m].v = cm - best2; }
         };
+        if (in_team) { team_resume(kTransfer); in_team = false; return true; }     // the transfer of all scanned rows, on the team; then the helpers go
         if (sr_rows.size() > 8) for (int32_t r : sr_rows) transfer(r);
         else transfer(i);
         if (par) release();
         return true;
     }
 
+    // ---- this search on a team of threads (Lsap: "one search on several threads"); this thread is member 0 ----------------
+    enum { kExpand = 0, kScanFar = 1, kRefill = 2, kWriteBack = 3, kOwnerStep = 4, kTransfer = 5, kLeave = 6 };
+    struct Team {
+        int size = 1;
+        std::atomic<int> arrived{0}, phase{0};
+        std::atomic<int> epoch{0}, gone{0};      // epoch: the team of search number `epoch` is set up; gone: helpers that have left it
+        int start_phase = 0;
+        std::atomic<size_t> cursor{0};
+        std::atomic<uint64_t> bound{0};          // distance << 24 | column: the nearest free column so far
+        int mode = kExpand, pending = kLeave;
+        int64_t theta = 0, delta = 1, min_val = 0;
+        int64_t bias = 0;                        // labels hold distance - bias: a fresh row's distances start below zero (its dual starts at 0)
+        // a bucket is drained without a barrier per hop: every member works off its own `near` list (what it pushes stays with
+        // it), a member that runs dry says so and takes from `pool`, into which busy members put half of a long list when
+        // somebody is hungry; the bucket is empty when all members are hungry and the pool is empty
+        std::mutex pool_m;
+        std::vector<int32_t> pool;
+        std::atomic<int> hungry{0};
+        std::atomic<bool> drained{false};
+        struct alignas(64) Slot {
+            std::vector<int32_t> near, far, touched, scanned;
+            size_t relax = 0, rows = 0, push = 0;
+            int64_t far_min = INF;
+        };
+        std::vector<Slot> slot;
+    } team;
+    inline uint64_t pack(int64_t d, int x) const { return ((uint64_t)(d - team.bias) << Lsap::kDistShift) | (uint32_t)x; }
+    inline int64_t dist_of(uint64_t lab) const { return (int64_t)(lab >> Lsap::kDistShift) + team.bias; }
+    void team_barrier(int &my_phase)
+    {
+        const int target = ++my_phase;
+        if (team.arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == team.size) {
+            team.arrived.store(0, std::memory_order_relaxed);
+            team.phase.store(target, std::memory_order_release);
+        } else {
+            int spins = 0;
+            while (team.phase.load(std::memory_order_acquire) - target < 0)
+                if (++spins > 4096) { std::this_thread::yield(); spins = 0; } else __builtin_ia32_pause();
+        }
+    }
+    static inline int64_t v_of(const Col &cj) { return __atomic_load_n(&cj.v, __ATOMIC_RELAXED); }
+    // the row of column j goes out to its options with the distance j holds now
+    void expand(int j, Team::Slot &me)
+    {
+        std::vector<Col> &c = L.c;
+        const std::vector<Row> &rw = L.rw;
+        const int n = L.n;
+        const int64_t d = dist_of(L.plabel[j].load(std::memory_order_relaxed));
+        int64_t bd = dist_of(team.bound.load(std::memory_order_relaxed));
+        if (d >= bd || d >= L.pexpanded[j]) return;
+        L.pexpanded[j] = d;                      // (two members may both get here for one column: the work is done twice, nothing else)
+        const int r = c[j].row;
+        const Row &rr = rw[r];
+        ++me.rows;
+        const int64_t off = d - rr.u;
+        auto relax = [&](int k, int64_t w) {
+            ++me.relax;
+            const int64_t rc = off + w - c[k].v;
+            if (rc >= bd) return;
+            const uint64_t lab = pack(rc, r);
+            std::atomic<uint64_t> &slot = L.plabel[k];
+            uint64_t old = slot.load(std::memory_order_relaxed);
+            for (;;) {                           // only a strictly smaller DISTANCE replaces a label: predecessor chains cannot close through arcs of reduced cost 0
+                if (old != Lsap::kNoLabel && rc >= dist_of(old)) return;
+                if (slot.compare_exchange_weak(old, lab, std::memory_order_relaxed)) break;
+            }
+            if (old == Lsap::kNoLabel) me.touched.push_back(k);
+            if (c[k].row < 0) {                  // a free column: the search ends there unless a nearer one turns up
+                const uint64_t b = pack(rc, k);
+                uint64_t ob = team.bound.load(std::memory_order_relaxed);
+                while (b < ob && !team.bound.compare_exchange_weak(ob, b, std::memory_order_relaxed)) {}
+                bd = std::min(bd, rc);
+            } else {
+                ++me.push;
+                (rc < team.theta ? me.near : me.far).push_back(k);
+            }
+        };
+        relax(r, 0);
+        relax(n + r, rr.own);
+        const Arc *ap = L.arcs.data() + rr.arc_begin;
+        for (int k = 0; k < rr.degree; ++k) {
+            const int64_t w = rr.base + ap[k].w;
+            if (off + w >= bd) break;            // column duals are <= 0: the bare cost bounds the reduced one
+            relax(ap[k].head, w);
+        }
+    }
+    int32_t arc_to(int r, int j) const           // the original index of the arc r -> in-slot j (-1: its own in-slot or its exit)
+    {
+        const Row &rr = L.rw[r];
+        if (j == r || j >= L.n) return -1;
+        const Arc *ap = L.arcs.data() + rr.arc_begin;
+        for (int k = 0; k < rr.degree; ++k) if (ap[k].head == j) return ap[k].id;
+        return -1;
+    }
+    // reduction transfer of one row (see insert_row_t), safe beside other rows' transfers: a row writes its own dual and its
+    // matched column's, and a stale (higher) dual read from another column only makes the raise smaller
+    void transfer_row_shared(int r)
+    {
+        std::vector<Col> &c = L.c;
+        Row &rr = L.rw[r];
+        const int n = L.n, m = rr.col;
+        int64_t best2 = INF, cm = 0;
+        auto see = [&](int j, int64_t w) { if (j == m) cm = w; else { const int64_t k = w - v_of(c[j]); if (k < best2) best2 = k; } };
+        see(r, 0);
+        see(n + r, rr.own);
+        const Arc *ap = L.arcs.data() + rr.arc_begin;
+        for (int k = 0; k < rr.degree; ++k) see(ap[k].head, rr.base + ap[k].w);
+        if (best2 < INF && best2 > rr.u) { rr.u = best2; __atomic_store_n(&c[m].v, cm - best2, __ATOMIC_RELAXED); }
+    }
+    // Every member of the team runs this, the owner as tid 0. A round = what team.mode says, a barrier, member 0 decides the
+    // next mode, a barrier. In kOwnerStep the owner leaves the loop for its serial work (dual update, augmentation) while the
+    // helpers wait at the round's first barrier; team_resume() brings it back.
+    int owner_ph = 0, team_sink_pred = -1;
+    bool in_team = false;
+    size_t par_next_try = 0;
+    // a helper: recruited before the owner knew the team's size, so it waits until the team is set up; says when it has left
+    void team_helper(int tid, int epoch)
+    {
+        int spins = 0;
+        while (team.epoch.load(std::memory_order_acquire) - epoch < 0)
+            if (++spins > 4096) { std::this_thread::yield(); spins = 0; } else __builtin_ia32_pause();
+        int ph = team.start_phase;
+        team_rounds(tid, ph);
+        team.gone.fetch_add(1, std::memory_order_release);
+    }
+    void team_rounds(int tid, int &ph)
+    {
+        Team::Slot &me = team.slot[tid];
+        std::vector<Col> &c = L.c;
+        constexpr size_t CH = 16;
+        for (;;) {
+            const int mode = team.mode;
+            if (mode == kLeave) return;
+            if (mode == kOwnerStep) {
+                if (tid == 0) return;
+            } else if (mode == kExpand) {
+                // drain this bucket
+                for (;;) {
+                    size_t since = 0;
+                    while (!me.near.empty()) {
+                        const int32_t j = me.near.back();
+                        me.near.pop_back();
+                        expand(j, me);
+                        if (++since >= 64) {
+                            since = 0;
+                            if (team.hungry.load(std::memory_order_relaxed) > 0 && me.near.size() >= 4 * CH) {
+                                std::lock_guard<std::mutex> g(team.pool_m);
+                                const size_t give = me.near.size() / 2;
+                                team.pool.insert(team.pool.end(), me.near.begin(), me.near.begin() + give);
+                                me.near.erase(me.near.begin(), me.near.begin() + give);
+                            }
+                        }
+                    }
+                    // dry: take from the pool, or wait until somebody gives or everybody is dry
+                    bool got = false;
+                    {
+                        std::unique_lock<std::mutex> g(team.pool_m);
+                        if (!team.pool.empty()) {
+                            const size_t take = std::min<size_t>(team.pool.size(), std::max<size_t>(CH, team.pool.size() / team.size));
+                            me.near.assign(team.pool.end() - take, team.pool.end());
+                            team.pool.resize(team.pool.size() - take);
+                            got = true;
+                        } else if (team.hungry.fetch_add(1, std::memory_order_relaxed) + 1 == team.size)
+                            team.drained.store(true, std::memory_order_release);
+                    }
+                    if (got) continue;
+                    int spins = 0;
+                    for (;;) {
+                        if (team.drained.load(std::memory_order_acquire)) break;
+                        if (!team.pool.empty()) {                              // (unlocked peek; checked again under the lock)
+                            std::unique_lock<std::mutex> g(team.pool_m);
+                            if (!team.pool.empty() && !team.drained.load(std::memory_order_relaxed)) {
+                                const size_t take = std::min<size_t>(team.pool.size(), std::max<size_t>(CH, team.pool.size() / team.size));
+                                me.near.assign(team.pool.end() - take, team.pool.end());
+                                team.pool.resize(team.pool.size() - take);
+                                team.hungry.fetch_sub(1, std::memory_order_relaxed);
+                                got = true;
+                                break;
+                            }
+                        }
+                        if (++spins > 2048) { std::this_thread::yield(); spins = 0; } else __builtin_ia32_pause();
+                    }
+                    if (!got) break;
+                }
+            } else if (mode == kScanFar || mode == kRefill) {
+                // kScanFar: drop what cannot matter any more, find the nearest label left; kRefill: the next bucket moves to `near`
+                const int64_t bd = dist_of(team.bound.load(std::memory_order_relaxed));
+                size_t keep = 0;
+                int64_t fmin = INF;
+                for (int32_t j : me.far) {
+                    const int64_t d = dist_of(L.plabel[j].load(std::memory_order_relaxed));
+                    if (d >= bd || d >= L.pexpanded[j]) continue;
+                    if (mode == kRefill && d < team.theta) { me.near.push_back(j); continue; }
+                    me.far[keep++] = j;
+                    if (d < fmin) fmin = d;
+                }
+                me.far.resize(keep);
+                me.far_min = fmin;
+            } else if (mode == kWriteBack) {
+                // the labels of the columns nearer than the free column go where the dual update and the augmentation read them
+                for (int32_t j : me.touched) {
+                    const uint64_t lab = L.plabel[j].load(std::memory_order_relaxed);
+                    const int64_t d = dist_of(lab);
+                    const int pr = (int)(lab & ((1u << Lsap::kDistShift) - 1));
+                    if (c[j].row >= 0 && d <= team.min_val) {        // (<=: the path may reach the free column over arcs of reduced cost 0)
+                        c[j].spc = d; c[j].pred_row = pr; c[j].pred_arc = arc_to(pr, j);
+                        me.scanned.push_back(j);
+                    }
+                    L.plabel[j].store(Lsap::kNoLabel, std::memory_order_relaxed);
+                    L.pexpanded[j] = INF;
+                }
+                me.touched.clear();
+            } else if (mode == kTransfer) {
+                size_t idx;
+                while ((idx = team.cursor.fetch_add(64, std::memory_order_relaxed)) < sr_rows.size())
+                    for (size_t q = idx; q < std::min(idx + 64, sr_rows.size()); ++q) transfer_row_shared(sr_rows[q]);
+            }
+            team_barrier(ph);
+            if (tid == 0) team_decide();
+            team_barrier(ph);
+        }
+    }
+    // the owner, back from its serial step: the team goes on with `next` (kTransfer, or kLeave: the helpers go home)
+    void team_resume(int next)
+    {
+        team.pending = next;
+        team.cursor.store(0, std::memory_order_relaxed);
+        team_barrier(owner_ph);                  // the first barrier of the kOwnerStep round, where the helpers wait
+        team_decide();
+        team_barrier(owner_ph);
+        team_rounds(0, owner_ph);
+        // the team's fields are reused by this thread's next large search: not before every helper is out of the loop
+        while (team.gone.load(std::memory_order_acquire) < team.size - 1) __builtin_ia32_pause();
+    }
+    // between the two barriers of a round, member 0 alone: what the team does next
+    void team_decide()
+    {
+        static const bool trace = getenv("AXT_MCF_TRACE") != nullptr;
+        if (trace) fprintf(stderr, "[par]   decide: mode %d theta %.4f bound %.4f\n", team.mode, (double)team.theta / 65536e6, (double)dist_of(team.bound.load()) / 65536e6);
+        if (team.mode == kExpand) {
+            team.mode = kScanFar;                // the bucket is empty: what is the nearest label left?
+        } else if (team.mode == kRefill) {
+            team.hungry.store(0, std::memory_order_relaxed);
+            team.drained.store(false, std::memory_order_relaxed);
+            team.mode = kExpand;
+        } else if (team.mode == kScanFar) {
+            int64_t gmin = INF;
+            for (const Team::Slot &sl : team.slot) gmin = std::min(gmin, sl.far_min);
+            const int64_t bd = dist_of(team.bound.load(std::memory_order_relaxed));
+            if (gmin >= bd) {                    // nothing left that is nearer than the free column: the search is over
+                team.min_val = bd;
+                const int sink = (int)(team.bound.load(std::memory_order_relaxed) & ((1u << Lsap::kDistShift) - 1));
+                team_sink_pred = (int)(L.plabel[sink].load(std::memory_order_relaxed) & ((1u << Lsap::kDistShift) - 1));
+                team.mode = kWriteBack;
+            } else {
+                team.theta = gmin + team.delta;
+                team.mode = kRefill;
+            }
+        } else if (team.mode == kWriteBack) {
+            team.mode = kOwnerStep;
+        } else if (team.mode == kOwnerStep) {
+            team.mode = team.pending;
+        } else if (team.mode == kTransfer) {
+            team.mode = kLeave;
+        }
+    }
+
+    // The search for row i has settled the columns sc_cols (the row of the last one, `cur`, not expanded yet) at distances up to
+    // minVal and holds open labels in its heap: the rest of it on a team of 1 + helpers threads. Returns the sink; minVal, the
+    // labels (Col::spc / pred_row / pred_arc), sr_rows and sc_cols are left as the serial search would have left them.
+    int finish_in_parallel(int i, int helpers, int64_t &minVal, int64_t best_free, uint32_t open)
+    {
+        std::vector<Col> &c = L.c;
+        const int n = L.n;
+        std::call_once(L.par_alloc, [&] {
+            L.plabel.reset(new std::atomic<uint64_t>[2 * (size_t)n]);
+            L.pexpanded.reset(new int64_t[2 * (size_t)n]);
+            for (size_t j = 0; j < 2 * (size_t)n; ++j) { L.plabel[j].store(Lsap::kNoLabel, std::memory_order_relaxed); L.pexpanded[j] = INF; }
+        });
+        team.size = 1 + helpers;
+        team.gone.store(0, std::memory_order_relaxed);
+        team.start_phase = owner_ph;             // (the barrier counters run on from search to search)
+        if ((int)team.slot.size() < team.size) team.slot.resize(team.size);
+        for (Team::Slot &sl : team.slot) { sl.near.clear(); sl.far.clear(); sl.touched.clear(); sl.scanned.clear(); sl.far_min = INF; }
+        team.pool.clear();
+        team.hungry.store(0, std::memory_order_relaxed);
+        team.drained.store(false, std::memory_order_relaxed);
+        Team::Slot &me = team.slot[0];
+        team.bias = c[sc_cols[0]].spc;           // the first column Dijkstra settled: no label is nearer
+        team.delta = std::max<int64_t>(1, (best_free - minVal) / L.par_buckets);
+        team.theta = minVal + team.delta;
+        uint64_t bound = Lsap::kNoLabel;
+        auto seed = [&](int j, bool expanded) {
+            const Col &cj = c[j];
+            L.plabel[j].store(pack(cj.spc, cj.pred_row), std::memory_order_relaxed);
+            L.pexpanded[j] = expanded ? cj.spc : INF;
+            me.touched.push_back(j);
+            if (expanded) return;
+            if (cj.row < 0) bound = std::min(bound, pack(cj.spc, j));
+            else (cj.spc < team.theta ? me.near : me.far).push_back(j);
+        };
+        for (size_t k = 0; k < sc_cols.size(); ++k) seed(sc_cols[k], k + 1 < sc_cols.size());
+        for (const Item &it : heap) {
+            const Col &cj = c[it.second];
+            if (cj.stamp == open && it.first == cj.spc && L.plabel[it.second].load(std::memory_order_relaxed) == Lsap::kNoLabel) seed(it.second, false);
+        }
+        heap.clear();
+        team.bound.store(bound, std::memory_order_relaxed);
+        team.cursor.store(0);
+        team.mode = kExpand;
+        if (me.near.size() > 64) {               // the open labels of the serial phase: shared out from the start
+            team.pool.assign(me.near.begin() + 32, me.near.end());
+            me.near.resize(32);
+        }
+        if (getenv("AXT_MCF_TRACE")) fprintf(stderr, "[par] row %d: team %d, closed %zu, near %zu far %zu, bound %.3f minVal %.3f theta %.3f\n", i, team.size, sc_cols.size(), me.near.size() + team.pool.size(), me.far.size(), (double)dist_of(bound) / 65536e6, (double)minVal / 65536e6, (double)team.theta / 65536e6);
+        team.epoch.fetch_add(1, std::memory_order_release);          // the helpers recruited for this search may come in
+        team_rounds(0, owner_ph);                // returns in kOwnerStep: the labels are written back, the helpers wait
+        minVal = team.min_val;
+        const int sink = (int)(team.bound.load(std::memory_order_relaxed) & ((1u << Lsap::kDistShift) - 1));
+        {   // the sink's label (it is not matched: the write-back skipped it; its label was reset there, so the predecessor
+            // comes from the bound's twin kept by the member that set it -- simplest: look it up among the scanned rows)
+            Col &cs = c[sink];
+            cs.spc = minVal;
+            cs.pred_row = team_sink_pred;
+            cs.pred_arc = arc_to(team_sink_pred, sink);
+        }
+        sc_cols.clear();
+        sr_rows.clear();
+        sr_rows.push_back(i);
+        for (Team::Slot &sl : team.slot) {
+            stat_relax += sl.relax; stat_push += sl.push; sl.relax = sl.push = sl.rows = 0;
+            for (int32_t j : sl.scanned) { sc_cols.push_back(j); sr_rows.push_back(c[j].row); }
+            sl.scanned.clear();
+        }
+        sc_cols.push_back(sink);
+        return sink;
+    }
     // rows in a fixed pseudo-random order (xorshift64 seeded by the first row: the same at any thread count)
     void insert_shuffled(int lo, int hi)
     {
@@ -517,7 +939,9 @@ struct Lsap {
         if (b - a == 1) {
             const double t0 = now_ms();
             Search w(*this, 0);
+            tasks_running.fetch_add(1, std::memory_order_relaxed);
             w.insert_shuffled(cut_q[a], cut_p[a + 1]);
+            tasks_running.fetch_sub(1, std::memory_order_relaxed);
             if (getenv("AXT_MCF_DEBUG")) fprintf(stderr, "  leaf %d: rows [%d,%d) scanned %zu, %.1f ms\n", a, cut_q[a], cut_p[a + 1], w.stat_rows, now_ms() - t0);
             return w.search + 2;
         }
@@ -535,7 +959,9 @@ struct Lsap {
         if (spawned) t.join();
         const double t0 = now_ms();
         Search w(*this, left > right ? left : right);
+        tasks_running.fetch_add(1, std::memory_order_relaxed);
         w.insert_shuffled(cut_p[m], cut_q[m]);
+        tasks_running.fetch_sub(1, std::memory_order_relaxed);
         if (getenv("AXT_MCF_DEBUG")) fprintf(stderr, "  separator %d (of leaves %d..%d): rows [%d,%d) scanned %zu, %.1f ms\n", m, a, b, cut_p[m], cut_q[m], w.stat_rows, now_ms() - t0);
         return w.search + 2;
     }
@@ -623,6 +1049,7 @@ struct Lsap {
             cut_p.assign(2, 0); cut_q.assign(2, 0);
             cut_p[1] = cut_q[1] = n;
         }
+        start_helpers();
         t_prep1 = now_ms();
     }
 
@@ -712,7 +1139,9 @@ struct Lsap {
                         if (t * per + q < again.size() && t * per + q < (t + 1) * per) dealt.push_back(again[t * per + q]);
                 again.swap(dealt);
             }
+            tasks_running.fetch_add(par, std::memory_order_relaxed);
             insert_concurrently(again, par);
+            tasks_running.fetch_sub(par, std::memory_order_relaxed);
             ends = again.size();
         }
         if (getenv("AXT_MCF_DEBUG"))
@@ -722,6 +1151,22 @@ struct Lsap {
                     budget, leaves, stat_rows, stat_relax, stat_push, stat_died, t1 - t0, now_ms() - t1);
     }
 };
+
+void Lsap::helper_main()
+{
+    for (;;) {
+        HelperPool::Job job;
+        {
+            std::unique_lock<std::mutex> lk(pool.m);
+            ++pool.idle;
+            pool.cv.wait(lk, [&] { return pool.quit || !pool.jobs.empty(); });
+            if (pool.jobs.empty()) { --pool.idle; return; }
+            job = pool.jobs.front();
+            pool.jobs.pop_front();
+        }
+        static_cast<Search *>(job.search)->team_helper(job.tid, job.epoch);
+    }
+}
 
 }  // namespace
 

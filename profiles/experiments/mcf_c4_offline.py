@@ -1,8 +1,12 @@
+"""The flow solve of BASELINE config 4 without a GPU: the detections of the synthetic 1024x1024x1024 timelapse (c4_dets.npz, dumped on
+the GPU box by profiles/dump_full_dets.py c4) -> the network as assign_ids builds it -> axt_mcf_solve.
+    python profiles/experiments/mcf_c4_offline.py [frames]      AXT_MCF_DEBUG=1 prints the tree; REPEAT=n"""
 import os, sys, time, numpy as np
-sys.path.insert(0, '/root/repo')
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, '..', '..'))
 from axtrack_amd import hotpath as hp
 from tests import helpers
-d = np.load('/tmp/c4_dets.npz')
+d = np.load(os.path.join(HERE, 'c4_dets.npz'))
 F = int(sys.argv[1]) if len(sys.argv) > 1 else len(d['count'])
 t=time.perf_counter()
 if os.path.exists(f'/tmp/c4_net_{F}.npz'):

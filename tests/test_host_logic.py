@@ -532,3 +532,33 @@ def test_shared_flow_solve_does_not_depend_on_a_ranks_thread_count_and_rejects_a
         with pytest.raises(_lib.AxtError):
             s0c.finish([s0c.state, other.state], 5, 100000)
     del s0b
+
+
+@pytest.mark.parametrize('threads', [2, 5])
+def test_a_large_search_finished_by_a_team_of_threads_changes_nothing(threads, monkeypatch):
+    """Search::finish_in_parallel (a search that has grown past a threshold goes on as a bucketed label-correcting search on
+    the idle threads): forced onto small networks with a threshold of a few dozen rows, it ends with the trajectories, the
+    cost and a valid optimality certificate of the serial solver -- static config-3 network (two phases, large second-phase
+    searches), a scene of moving cones, one-phase schedule, and the solve shared between two ranks."""
+    from helpers import c3_network, moving_network, check_flow_certificate
+    nets = [(c3_network()[:6], 5, 450), (moving_network(100, 512, 90, seed=11)[:6], 5, 100000)]
+    monkeypatch.setenv('AXT_MCF_THREADS', str(threads))
+    for net, lo, hi in nets:
+        monkeypatch.setenv('AXT_MCF_NO_PAR_SEARCH', '1')
+        ref = hp.mcf_solve(*net, lo, hi)
+        monkeypatch.delenv('AXT_MCF_NO_PAR_SEARCH')
+        monkeypatch.setenv('AXT_MCF_PAR_MIN_N', '0')
+        for switch, buckets, extra in ((48, 7, {}), (300, 48, {'AXT_MCF_ONE_PHASE': '1'})):
+            monkeypatch.setenv('AXT_MCF_PAR_SWITCH', str(switch))
+            monkeypatch.setenv('AXT_MCF_PAR_BUCKETS', str(buckets))
+            for k, v in extra.items():
+                monkeypatch.setenv(k, v)
+            got = hp.mcf_solve(*net, lo, hi, duals=True)
+            for k in extra:
+                monkeypatch.delenv(k)
+            assert got[2] == ref[2] and got[3] == ref[3] and np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+            check_flow_certificate(*net, got[0], got[1], got[3], got[4], lo, hi)
+        shards = [hp.McfShard(*net, r, 2) for r in range(2)]
+        res = shards[1].finish([s.state for s in shards], lo, hi)
+        assert res[3] == ref[3] and np.array_equal(res[1], ref[1])
+        monkeypatch.delenv('AXT_MCF_PAR_MIN_N')
