@@ -583,10 +583,24 @@ __device__ __forceinline__ void wino_body(const float *__restrict__ in, const fl
     float *Vs = smem, *Us = smem + 2 * G::VBUF;
     auto group_of = [&](int w) { return NG == 1 ? 0 : (w / ntile) % NG; };
 
-    float bias_v[NTW];
+    // Which operand is which decides what a lane holds and hence how its results leave:
+    //   pooled blocks:   A = V, B = U: D[tile 4q + r][channel p] -- a lane holds one channel and four x-adjacent tiles = four
+    //                    adjacent POOLED pixels, one 16-byte store per channel block;
+    //   unpooled blocks: A = U, B = V: D[channel 4q + r][tile p] -- a lane holds ONE tile (row 2m + p/8, column p%8 of the
+    //                    workgroup's 8 x 8 tiles) and four consecutive channels; the 8 lanes of a tile row own 8 x-adjacent
+    //                    tiles = one whole 64-byte line of an output row per channel, so a store instruction writes 8 whole
+    //                    lines instead of 64 separate 16-byte pieces.
+    // Interleaved A/B on one box (profiles/r04f_ab_stores.log, r04g_*): the second layout is 2 % faster on the unpooled blocks
+    // and 2 % slower on the pooled ones (four 4-byte stores per channel block instead of one 16-byte store), so each kind keeps
+    // the layout that suits it. Same products in the same k order either way: the results do not depend on it.
+    constexpr bool TILE_LANES = !POOL;              // lane = tile, registers = four channels
+    f32x4 bias_v[NTW];
     auto load_bias = [&](int grp) {
 #pragma unroll
-        for (int n = 0; n < NTW; ++n) bias_v[n] = bias[grp * 80 + (N0 + n) * 16 + p];
+        for (int n = 0; n < NTW; ++n) {
+            if constexpr (TILE_LANES) bias_v[n] = *reinterpret_cast<const f32x4 *>(bias + grp * 80 + (N0 + n) * 16 + 4 * q);
+            else { const float bv = bias[grp * 80 + (N0 + n) * 16 + p]; bias_v[n] = f32x4{bv, bv, bv, bv}; }
+        }
     };
     load_bias(group_of(wr.begin));
 
@@ -721,7 +735,7 @@ __device__ __forceinline__ void wino_body(const float *__restrict__ in, const fl
             for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int n = 0; n < NTW; ++n)
-                    acc[pos][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[slot][s], bq[slot][n][s],
+                    acc[pos][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(TILE_LANES ? bq[slot][n][s] : a[slot][s], TILE_LANES ? a[slot][s] : bq[slot][n][s],
                                                                        (FIRST && s == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[pos][n], 0, 0, 0);
             int nvm = 0;
             if constexpr (XFORM) {
@@ -744,13 +758,24 @@ __device__ __forceinline__ void wino_body(const float *__restrict__ in, const fl
     auto epilogue = [&](int w) {
         const int tile = w % ntile, b = w / (ntile * NG), grp = group_of(w);
         const int y0 = (tile / tiles_x) * 16, x0 = (tile % tiles_x) * 16;
-        const int ty = 2 * m + (q >> 1), txb = 4 * (q & 1);          // this lane's tiles: row ty, columns txb .. txb + 3
+        // TILE_LANES: this lane's tile (ty, tx), channels ch .. ch + 3 in the registers; else: its channel ch, tiles (ty, tx .. tx + 3)
+        const int ty = TILE_LANES ? 2 * m + (p >> 3) : 2 * m + (q >> 1), tx = TILE_LANES ? (p & 7) : 4 * (q & 1);
+        const long plane = (long)Hout * Hout;
+#ifndef AXT_WINO_PK_EPILOGUE
+        // one plain v_add / v_sub per element, as in the input transform: packed f32 arithmetic is slow beside the partner
+        // wave's MFMAs (profiles/r04g_ab_epilogue.log)
+        auto fadd = [](float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+        auto fsub = [](float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+#endif
 #pragma unroll
         for (int n = 0; n < NTW; ++n) {
-            const int ch = (N0 + n) * 16 + p;
-            float *och = out + ((long)b * (80 * NG) + grp * 80 + ch) * Hout * Hout;
-            // 4-vectors over the lane's four tiles (the accumulator registers of one position): packed adds on aligned pairs
-            f32x4 t[2][4], y[2][2];
+            const int ch = (N0 + n) * 16 + (TILE_LANES ? 4 * q : p);
+            float *och = out + ((long)b * (80 * NG) + grp * 80 + ch) * plane;
+            // the four elements of an accumulator register quadruple (four channels of a tile, or four tiles of a channel) go
+            // through A^T M A, the bias and LeakyReLU(0.1) side by side
+            f32x4 y[2][2];
+#ifdef AXT_WINO_PK_EPILOGUE
+            f32x4 t[2][4];
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 t[0][jj] = acc[jj][n] + acc[4 + jj][n] + acc[8 + jj][n];
@@ -769,6 +794,24 @@ __device__ __forceinline__ void wino_body(const float *__restrict__ in, const fl
 #pragma unroll
                     for (int j = 0; j < 4; ++j) y[a][bb][j] = fmaxf(tb[j], tb[j] * 0.1f);      // LeakyReLU(0.1) = max(t, 0.1 t)
                 }
+#else
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t[2][4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    t[0][jj] = fadd(fadd(acc[jj][n][j], acc[4 + jj][n][j]), acc[8 + jj][n][j]);
+                    t[1][jj] = fsub(fsub(acc[4 + jj][n][j], acc[8 + jj][n][j]), acc[12 + jj][n][j]);
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const float y0v = fadd(fadd(t[a][0], t[a][1]), t[a][2]), y1v = fsub(fsub(t[a][1], t[a][2]), t[a][3]);
+                    const float tb0 = fadd(y0v, bias_v[n][j]), tb1 = fadd(y1v, bias_v[n][j]);
+                    y[a][0][j] = fmaxf(tb0, tb0 * 0.1f);                                        // LeakyReLU(0.1) = max(t, 0.1 t)
+                    y[a][1][j] = fmaxf(tb1, tb1 * 0.1f);
+                }
+            }
+#endif
             if constexpr (POOL) {
                 f32x4 r;
 #pragma unroll
@@ -776,17 +819,17 @@ __device__ __forceinline__ void wino_body(const float *__restrict__ in, const fl
 #ifdef AXT_WINO_NO_STORE              // diagnostic build (timing only, wrong results): the epilogue without its stores
                 if (r[0] == 12345.678f)
 #endif
-                *reinterpret_cast<f32x4 *>(och + (long)(y0 / 2 + ty) * Hout + x0 / 2 + txb) = r;
+                *reinterpret_cast<f32x4 *>(och + (long)(y0 / 2 + ty) * Hout + x0 / 2 + tx) = r;
             } else {
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
-                    float *orow = och + (long)(y0 + 2 * ty + a) * Hout + x0 + 2 * txb;
+                    float *orow = och + (long)(y0 + 2 * ty + a) * Hout + x0 + 2 * tx;
 #ifdef AXT_WINO_NO_STORE
                     if (y[a][0][0] == 12345.678f)
 #endif
                     {
-                    *reinterpret_cast<f32x4 *>(orow) = f32x4{y[a][0][0], y[a][1][0], y[a][0][1], y[a][1][1]};
-                    *reinterpret_cast<f32x4 *>(orow + 4) = f32x4{y[a][0][2], y[a][1][2], y[a][0][3], y[a][1][3]};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x2 *>(orow + j * plane) = f32x2{y[a][0][j], y[a][1][j]};
                     }
                 }
             }
