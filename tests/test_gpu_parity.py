@@ -2065,3 +2065,28 @@ def test_the_references_example_sequence_with_only_the_import_changed(tmp_path, 
     assert n == 8 and p.getnnz() == 8
     with pytest.raises(ValueError, match='mask weights'):
         axtrack._compute_astar_path((5, 5), (9, 2), np.full((16, 16), 3.0, np.float32))
+
+
+def test_a_second_device_in_one_process_gets_its_own_launch_attributes(weights, golden):
+    """Detector(device='cuda:1') beside one on cuda:0 (and the decode / association kernels there): every launcher sets its
+    >64 KB LDS attribute per device (AxtOncePerDevice). Needs two GPUs; the one-GPU boxes of the pool skip it -- the table
+    itself is unit-tested on the host (tests/test_host_logic.py)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('one GPU on this box')
+    import axtrack_amd
+    g = golden('cnn_512')
+    outs = []
+    for dev in ('cuda:0', 'cuda:1', 'cuda:0'):
+        det = axtrack_amd.Detector(weights, max_batch=8, device=dev)
+        X = torch.from_numpy(g['X']).to(dev)
+        outs.append(det.detect_axons(X).cpu().numpy())
+        frames = torch.from_numpy(synth.synth_frames(9, 512, 512, seed=3))
+        tl = axtrack_amd.Timelapse(frames, name='dev', device=dev)
+        P = params.load_parameters()
+        P['DEVICE'] = dev
+        P['MCF_MIN_FLOW'] = 1
+        for assoc in ('hungarian', 'mcf'):
+            P['ASSOCIATION'] = assoc
+            ad = axtrack_amd.inference(tl, det, None, P, None, None, None)
+            assert ad.IDed_dets_all.shape[1] == 3 * 5
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])

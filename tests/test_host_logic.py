@@ -562,3 +562,39 @@ def test_a_large_search_finished_by_a_team_of_threads_changes_nothing(threads, m
         res = shards[1].finish([s.state for s in shards], lo, hi)
         assert res[3] == ref[3] and np.array_equal(res[1], ref[1])
         monkeypatch.delenv('AXT_MCF_PAR_MIN_N')
+
+
+def test_launch_attributes_are_remembered_per_device_not_per_process(tmp_path):
+    """hipFuncSetAttribute acts on the CURRENT device: the launchers remember per device index what they have set
+    (AxtOncePerDevice, csrc/axt_common.h) instead of in one process-wide flag, so a second device in one process gets its own
+    attributes (a >64 KB LDS kernel launched on cuda:1 without them fails). The table itself, on the host: a device's bit is
+    set by mark() only, other devices stay pending, indices beyond 63 are never cached; without a visible device every call
+    is pending (nothing is remembered for a device that could not be asked)."""
+    import subprocess
+    src = tmp_path / 'once.cpp'
+    src.write_text(r'''
+#include "axt_common.h"
+void axt_set_error(const char *, ...) {}
+int main()
+{
+    AxtOncePerDevice once;
+    int n = 0;
+    const bool have = hipGetDeviceCount(&n) == hipSuccess && n > 0;
+    if (!once.pending()) return 1;                       // nothing set yet
+    if (!have) { once.mark(); if (!once.pending()) return 2; }      // no device: never remembered
+    once.dev = 3; once.mark();
+    if (once.done.load() != (have ? (1ull << 3) | 0ull : 1ull << 3) && once.done.load() != ((1ull << 3) | 1ull)) return 3;
+    once.dev = 5;
+    if ((once.done.load() >> 5) & 1) return 4;           // another device is still pending
+    once.mark();
+    if (!((once.done.load() >> 5) & 1) || !((once.done.load() >> 3) & 1)) return 5;
+    once.dev = 64; const unsigned long long before = once.done.load(); once.mark();
+    if (once.done.load() != before) return 6;            // beyond the table: set up on every call
+    return 0;
+}
+''')
+    exe = tmp_path / 'once'
+    csrc = os.path.join(ROOT, 'axtrack_amd', 'csrc')
+    subprocess.check_call(['/opt/rocm/bin/hipcc', '-x', 'c++', '-std=c++17', '-D__HIP_PLATFORM_AMD__', '-I/opt/rocm/include', f'-I{csrc}', str(src), '-o', str(exe),
+                           '-L/opt/rocm/lib', '-lamdhip64', '-Wl,-rpath,/opt/rocm/lib'])
+    assert subprocess.run([str(exe)]).returncode == 0
