@@ -810,15 +810,21 @@ class AxonDetections(object):
                                                                       shard[2])
         offs = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
         n_det = int(offs[-1])
-        obs_h = obs.cpu().numpy()
-        valid = np.arange(conf.shape[1])[None, :] < cnt[:, None]
-        obs_flat = obs_h[valid]
-        k = np.arange(n_det, dtype=np.int64)
-        obs_int = _arc_cost_int_vec(obs_flat, 2, k, 0)
+        # the integer node costs (axt_arc_cost_int: round(cost * 1e6) << 16 | identity hash) on the device, beside the arcs' (the
+        # numpy version of the same arithmetic took 57 ms for config 4's 319 k detections); entry / exit depend on the count
+        # and the price only and are kept
+        valid = torch.arange(conf.shape[1], device=self.device)[None, :] < self.d_count[:, None]
+        k = torch.arange(n_det, dtype=torch.int64, device=self.device)
+        obs_int = _arc_cost_int_torch(torch.round(obs[valid] * 1e6).to(torch.int64), 2, k, 0)
         ee = float(P['MCF_ENTRY_EXIT_COST'])
-        entry_int = _arc_cost_int_vec(np.full(n_det, ee), 0, k, 0)
-        exit_int = _arc_cost_int_vec(np.full(n_det, ee), 1, k, 0)
-        net = (obs_int, entry_int, exit_int, *hp.to_host(row_ptr[:n_det + 1], col, cost))       # (pinned staging: 120 MB at config 4)
+        key = (n_det, ee, str(self.device))
+        if _ENTRY_EXIT_CACHE.get('key') != key:
+            units = torch.full((n_det,), int(np.rint(ee * 1e6)), dtype=torch.int64, device=self.device)
+            _ENTRY_EXIT_CACHE.update(key=key, entry=_arc_cost_int_torch(units, 0, k, 0).cpu().numpy(),
+                                     exit=_arc_cost_int_torch(units, 1, k, 0).cpu().numpy())
+        entry_int, exit_int = _ENTRY_EXIT_CACHE['entry'], _ENTRY_EXIT_CACHE['exit']
+        obs_int, row_ptr_h, col_h, cost_h = hp.to_host(obs_int, row_ptr[:n_det + 1], col, cost)       # (pinned staging: 120 MB at config 4)
+        net = (obs_int, entry_int, exit_int, row_ptr_h, col_h, cost_h)
         # parameters['MCF_CERTIFICATE'] (not a key of the reference): also return the node potentials that prove the optimum
         # (axt_mcf_solve_duals) and keep them, with the network they refer to, in self.mcf_certificate
         want_cert = bool(P.get('MCF_CERTIFICATE', False))
@@ -830,7 +836,7 @@ class AxonDetections(object):
         else:
             res = hp.mcf_solve(*net, P['MCF_MIN_FLOW'], P['MCF_MAX_FLOW'], duals=want_cert)
         if res is not None and want_cert:
-            self.mcf_certificate = dict(obs=net[0], entry=net[1], exit=net[2], row_ptr=net[3].copy(), col=net[4].copy(),
+            self.mcf_certificate = dict(obs=net[0].copy(), entry=net[1], exit=net[2], row_ptr=net[3].copy(), col=net[4].copy(),
                                         cost=net[5].copy(), next=res[0], track=res[1], total_cost=res[3], potentials=res[4],
                                         min_flow=P['MCF_MIN_FLOW'], max_flow=P['MCF_MAX_FLOW'])
             res = res[:4]
@@ -964,6 +970,7 @@ class AxonDetections(object):
 
 _COLUMNS_CACHE = {}
 _UNITS_CACHE = {}
+_ENTRY_EXIT_CACHE = {}          # the integer entry / exit costs of the last (detection count, price, device)
 _IDS_GUESS = {}                 # (frames, capacity) -> rows to build IDed_dets_all for before the count is known
 _COUNT_BUF = []
 
