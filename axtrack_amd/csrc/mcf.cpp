@@ -1275,6 +1275,11 @@ static int mcf_solve_impl(int n_det, const int64_t *h_obs, const int64_t *h_entr
             // Johnson update pi'[x] = pi[x] + min(dist[x], dT) keeps every residual reduced cost >= 0. Adding
             // the same constant to all potentials changes no reduced cost, so instead of +dT on the (many)
             // nodes the search never touched, the touched ones get min(dist, dT) - dT <= 0.
+            if (getenv("AXT_MCF_SSP_STATS")) {          // how much of the shortest-path tree an augmentation invalidates (the work muSSP cannot avoid)
+                size_t changed = 0, settled = 0;
+                for (int32_t x : s.touched) { if (s.dist[x] <= dT) { ++settled; if (s.dist[x] > 0) ++changed; } }
+                fprintf(stderr, "ssp path %d: cost %.3f, touched %zu, settled %zu, distance changed %zu of %d nodes\n", F, (double)(path_cost >> 16) * 1e-6, s.touched.size(), settled, changed, 2 * n_det + 2);
+            }
             for (int32_t x : s.touched) s.pi[x] += (s.dist[x] < dT ? s.dist[x] : dT) - dT;
             s.augment();
             total += path_cost;
