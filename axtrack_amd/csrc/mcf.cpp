@@ -1021,7 +1021,8 @@ struct Lsap {
         leaves = 1;
         // shared between ranks: every rank must build the SAME tree, so nothing of this process (its CPU set, its environment's
         // thread count) may enter the leaf count -- a fixed 16 leaves per rank, the thread budget of a one-GPU share
-        const int cap_leaves = world > 1 ? 16 * world : budget;
+        int cap_leaves = world > 1 ? 16 * world : budget;
+        if (const char *e = getenv("AXT_MCF_LEAVES")) cap_leaves = atoi(e) >= 1 ? atoi(e) : 1;       // (experiments: more leaves than threads)
         while (leaves * 2 <= cap_leaves && n / (leaves * 2) >= kMinLeaf) leaves *= 2;
         for (; leaves > 1; leaves /= 2) {
             cut_p.assign(leaves + 1, 0);

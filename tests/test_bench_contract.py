@@ -170,3 +170,37 @@ def test_committed_counters_are_withheld_when_sources_or_command_differ(tmp_path
         f.write('\n// edited\n')
     got = b.committed_counters(table, 'conv2 40>80 +pool', True, wino, 4.0, args)
     assert got['traffic'] is None and 'sources have changed' in got['counters_withheld'][0]
+
+
+def test_round_4_lines_c4_c5_certificate_steady_state_and_matching_counters():
+    """Round 4 (profiles/r04j_bench*.json, counters from the set r04h): the driver's line carries counters only because the set's
+    meta file matches its kernel sources and command; the lines of other commands say why theirs are withheld; BASELINE configs 4
+    and 5 have lines of their own, verified through the flow certificate over all arcs; every line says what its timed passes
+    reuse and what one pass over a fresh timelapse object takes."""
+    b = json.load(open(os.path.join(ROOT, 'profiles', 'r04j_bench.json')))
+    assert b['verified'] is True and b['n_gpus'] == 1 and b['steps'] == 20 and abs(b['value'] - 252e3 / b['ms_per_step']) / b['value'] < 1e-3
+    r = b['roofline']
+    assert r['mfma_busy']['source'] == 'profiles/r04h_pmc.csv' and r['hbm_gbps']['source'] == 'profiles/r04h_kernels.csv'
+    assert 'counters_withheld' not in r and 0.6 < r['mfma_busy']['kernel'] < 0.8 and 0.6 < r['frac'] < 0.75
+    ss = b['config']['steady_state']
+    assert ss['fresh_timelapse_pass_ms'] > b['ms_per_step'] and 'identity count' in ss['what'] and 'kept-tile list' in ss['what']
+    meta = json.load(open(os.path.join(ROOT, 'profiles', 'r04h_meta.json')))
+    assert len(meta['sources_sha256']) == 64 and meta['workload_key']['workload'] == 'c3'
+    rows = list(csv.DictReader(open(os.path.join(ROOT, 'profiles', 'r04h_kernels.csv'))))
+    dom = next(q for q in rows if 'wino<40->80' in q['kernel'])
+    assert abs(float(dom['avg_us']) / 1e3 - r['avg_launch_ms']) / r['avg_launch_ms'] < 0.12
+    m = json.load(open(os.path.join(ROOT, 'profiles', 'r04j_bench_mcf.json')))
+    assert m['verified'] is True and m['verify']['flow_certificate']['ok'] is True and m['roofline']['mfma_busy'] is None
+    assert 'collected for' in m['roofline']['counters_withheld'][0]
+    for wl, frames, arcs in (('c4', 128, 1000000), ('c5', 64, 500000)):
+        q = json.load(open(os.path.join(ROOT, 'profiles', f'r04j_bench_{wl}.json')))
+        assert q['verified'] is True and q['config']['detection_frames_per_gpu'] == frames and q['config']['tiles_per_frame'] == 4
+        assert f'BASELINE config {wl[1]}' in q['config']['workload'] and '1 of 8 GPU shares' in q['config']['workload']
+        v = q['verify']
+        assert v['flow_certificate']['ok'] is True and v['flow_certificate']['arcs'] > arcs and v['arc_rows_vs_oracle']['ok'] is True
+        assert v['detections_bit_exact_frames'] == frames and v['cnn_max_rel_err'] < 1e-5
+        assert q['cpu_baseline']['kind'] == 'port' and q['cpu_baseline']['value'] > 0 and q['roofline']['bound'] == 'mfma'
+        assert abs(q['value'] - frames * 1e3 / q['ms_per_step']) / q['value'] < 1e-3
+    assert 'EXTRAPOLATED' in json.load(open(os.path.join(ROOT, 'profiles', 'r04j_bench_c5.json')))['cpu_baseline']['sample']
+    two = json.load(open(os.path.join(ROOT, 'profiles', 'r04j_bench_2ranks_c4.json')))
+    assert two['n_gpus'] == 2 and two['tracks_identical_on_all_ranks'] is True and two['verify']['flow_certificate']['ok'] is True

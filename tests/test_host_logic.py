@@ -421,12 +421,12 @@ def test_bench_reads_the_committed_counters_of_the_newest_round():
                                                    ('conv5 80>80 +pool', 2), ('conv7 80>80', 1), ('conv8 80>80 +pool', 1), ('conv10 80>160', 1))]
     wino = ('conv2', 'conv4', 'conv5', 'conv7', 'conv8', 'conv10')
     got = bench.committed_counters(table, 'conv2 40>80 +pool', True, wino, 3.85)
-    assert got['mfma_busy']['source'] == 'profiles/r03zz_pmc.csv' and 0.6 < got['mfma_busy']['kernel'] < 0.8
-    assert got['hbm_gbps']['source'] == 'profiles/r03zz_kernels.csv' and got['traffic'] > 4e8
+    assert got['mfma_busy']['source'] == 'profiles/r04h_pmc.csv' and 0.6 < got['mfma_busy']['kernel'] < 0.8
+    assert got['hbm_gbps']['source'] == 'profiles/r04h_kernels.csv' and got['traffic'] > 4e8
     # the two stride-2 blocks as one kernel: the bench's row 'conv0+1 ... fused' <-> the profile's conv_s2_fused
     fused_table = [dict(name='conv0+1 5>20>40 s2 fused', launches=2), dict(name='conv1 20>40 s2', launches=0)] + table[2:]
     f = bench.committed_counters(fused_table, 'conv0+1 5>20>40 s2 fused', True, wino, 3.6)
-    assert f['mfma_busy']['source'] == 'profiles/r03zz_pmc.csv' and 0.6 < f['mfma_busy']['kernel'] < 0.8
+    assert f['mfma_busy']['source'] == 'profiles/r04h_pmc.csv' and 0.6 < f['mfma_busy']['kernel'] < 0.8
     assert 3e8 < f['traffic'] < 6e8 and f['hbm_gbps']['whole_cnn'] > 0
     assert bench.committed_counters(table, 'conv0 5>20 s2', True, wino, 3.85)['hbm_gbps']['source'] == 'profiles/r03z_kernels.csv'
     direct = bench.committed_counters(table, 'conv2 40>80 +pool', False, wino, 5.6)       # the direct kernels of the variant pass
