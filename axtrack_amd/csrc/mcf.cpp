@@ -541,6 +541,7 @@ struct Lsap {
         // somebody is hungry; the bucket is empty when all members are hungry and the pool is empty
         std::mutex pool_m;
         std::vector<int32_t> pool;
+        std::atomic<size_t> pool_size{0};        // (what a dry member peeks at without the lock)
         std::atomic<int> hungry{0};
         std::atomic<bool> drained{false};
         struct alignas(64) Slot {
@@ -573,8 +574,8 @@ struct Lsap {
         const int n = L.n;
         const int64_t d = dist_of(L.plabel[j].load(std::memory_order_relaxed));
         int64_t bd = dist_of(team.bound.load(std::memory_order_relaxed));
-        if (d >= bd || d >= L.pexpanded[j]) return;
-        L.pexpanded[j] = d;                      // (two members may both get here for one column: the work is done twice, nothing else)
+        if (d >= bd || d >= __atomic_load_n(&L.pexpanded[j], __ATOMIC_RELAXED)) return;
+        __atomic_store_n(&L.pexpanded[j], d, __ATOMIC_RELAXED);      // (two members may both get here for one column: the work is done twice, nothing else)
         const int r = c[j].row;
         const Row &rr = rw[r];
         ++me.rows;
@@ -674,6 +675,7 @@ struct Lsap {
                                 const size_t give = me.near.size() / 2;
                                 team.pool.insert(team.pool.end(), me.near.begin(), me.near.begin() + give);
                                 me.near.erase(me.near.begin(), me.near.begin() + give);
+                                team.pool_size.store(team.pool.size(), std::memory_order_release);
                             }
                         }
                     }
@@ -685,6 +687,7 @@ struct Lsap {
                             const size_t take = std::min<size_t>(team.pool.size(), std::max<size_t>(CH, team.pool.size() / team.size));
                             me.near.assign(team.pool.end() - take, team.pool.end());
                             team.pool.resize(team.pool.size() - take);
+                            team.pool_size.store(team.pool.size(), std::memory_order_release);
                             got = true;
                         } else if (team.hungry.fetch_add(1, std::memory_order_relaxed) + 1 == team.size)
                             team.drained.store(true, std::memory_order_release);
@@ -693,12 +696,13 @@ struct Lsap {
                     int spins = 0;
                     for (;;) {
                         if (team.drained.load(std::memory_order_acquire)) break;
-                        if (!team.pool.empty()) {                              // (unlocked peek; checked again under the lock)
+                        if (team.pool_size.load(std::memory_order_acquire) > 0) {     // (a peek; checked again under the lock)
                             std::unique_lock<std::mutex> g(team.pool_m);
                             if (!team.pool.empty() && !team.drained.load(std::memory_order_relaxed)) {
                                 const size_t take = std::min<size_t>(team.pool.size(), std::max<size_t>(CH, team.pool.size() / team.size));
                                 me.near.assign(team.pool.end() - take, team.pool.end());
                                 team.pool.resize(team.pool.size() - take);
+                                team.pool_size.store(team.pool.size(), std::memory_order_release);
                                 team.hungry.fetch_sub(1, std::memory_order_relaxed);
                                 got = true;
                                 break;
@@ -715,7 +719,7 @@ struct Lsap {
                 int64_t fmin = INF;
                 for (int32_t j : me.far) {
                     const int64_t d = dist_of(L.plabel[j].load(std::memory_order_relaxed));
-                    if (d >= bd || d >= L.pexpanded[j]) continue;
+                    if (d >= bd || d >= __atomic_load_n(&L.pexpanded[j], __ATOMIC_RELAXED)) continue;
                     if (mode == kRefill && d < team.theta) { me.near.push_back(j); continue; }
                     me.far[keep++] = j;
                     if (d < fmin) fmin = d;
@@ -809,6 +813,7 @@ struct Lsap {
         if ((int)team.slot.size() < team.size) team.slot.resize(team.size);
         for (Team::Slot &sl : team.slot) { sl.near.clear(); sl.far.clear(); sl.touched.clear(); sl.scanned.clear(); sl.far_min = INF; }
         team.pool.clear();
+        team.pool_size.store(0, std::memory_order_relaxed);
         team.hungry.store(0, std::memory_order_relaxed);
         team.drained.store(false, std::memory_order_relaxed);
         Team::Slot &me = team.slot[0];
@@ -837,6 +842,7 @@ struct Lsap {
         if (me.near.size() > 64) {               // the open labels of the serial phase: shared out from the start
             team.pool.assign(me.near.begin() + 32, me.near.end());
             me.near.resize(32);
+            team.pool_size.store(team.pool.size(), std::memory_order_relaxed);
         }
         if (getenv("AXT_MCF_TRACE")) fprintf(stderr, "[par] row %d: team %d, closed %zu, near %zu far %zu, bound %.3f minVal %.3f theta %.3f\n", i, team.size, sc_cols.size(), me.near.size() + team.pool.size(), me.far.size(), (double)dist_of(bound) / 65536e6, (double)minVal / 65536e6, (double)team.theta / 65536e6);
         team.epoch.fetch_add(1, std::memory_order_release);          // the helpers recruited for this search may come in
