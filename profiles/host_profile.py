@@ -12,7 +12,7 @@ frames = synth.synth_frames(256, 512, 512, seed=0)
 sd = synth.synth_state_dict(42)
 model = axtrack_amd.Detector(sd, max_batch=252)
 tl = axtrack_amd.Timelapse(frames, name='c3')
-P = dict(params.load_parameters(), ASSOCIATION='hungarian')
+P = dict(params.load_parameters(), ASSOCIATION=(sys.argv[1] if len(sys.argv) > 1 else 'hungarian'))
 
 def step():
     ad = axtrack_amd.AxonDetections(model, tl, P, None)
