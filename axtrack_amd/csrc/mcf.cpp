@@ -309,7 +309,6 @@ struct Lsap {
     struct Search {
     Lsap &L;
     std::vector<int32_t> sr_rows, sc_cols;
-    std::vector<Item> heap;                           // min-heap of (key, column), storage reused
     uint32_t search;                                  // stamps above every stamp already left in this task's columns
     size_t stat_rows = 0, stat_relax = 0, stat_push = 0, stat_died = 0;
     int32_t ticket = 0;                               // > 0: concurrent mode (claims), smaller = older
@@ -354,41 +353,81 @@ struct Lsap {
         for (int32_t j : claimed) L.owner[j].store(0, std::memory_order_release);
         claimed.clear();
     }
-    // 4-ary min-heap with lazy deletion (stale entries are skipped when popped)
-    void heap_push(Item it)
-    {
-        size_t k = heap.size();
-        heap.push_back(it);
-        while (k > 0) {
-            const size_t p = (k - 1) >> 2;
-            if (heap[p].first <= it.first) break;
-            heap[k] = heap[p];
-            k = p;
-        }
-        heap[k] = it;
-    }
-    Item heap_pop()
-    {
-        const Item top = heap[0], last = heap.back();
-        heap.pop_back();
-        const size_t m = heap.size();
-        if (m) {
-            size_t k = 0;
-            for (;;) {
-                const size_t c0 = 4 * k + 1;
-                if (c0 >= m) break;
-                size_t best = c0;
-                const size_t ce = c0 + 4 < m ? c0 + 4 : m;
-                for (size_t q = c0 + 1; q < ce; ++q)
-                    if (heap[q].first < heap[best].first) best = q;
-                if (last.first <= heap[best].first) break;
-                heap[k] = heap[best];
-                k = best;
+    // Monotone radix heap with lazy deletion (stale entries are skipped when popped). A Dijkstra search never pushes a key
+    // below the last one it popped (reduced costs are >= 0), so an entry can be filed by the highest bit in which its key
+    // differs from that last key: a push is one append, a pop takes from the bucket of equal keys and, when that is empty,
+    // spreads the lowest occupied bucket over the buckets below it around its smallest key. Keys pushed before the first pop
+    // (the fresh row's own options, whose distances may lie below zero) wait in a staging bucket.
+    struct RadixHeap {
+        static constexpr int kStage = 65;
+        std::vector<Item> b[66];
+        uint64_t occupied = 0;                 // bit k: b[k] is not empty (k = 0..64 -> bits 0..63 for k <= 63; b[64] tracked apart)
+        bool top_bucket = false;               // b[64] not empty
+        uint64_t last = 0;
+        bool started = false;
+        size_t count = 0;
+        static inline uint64_t ukey(int64_t k) { return (uint64_t)k ^ ((uint64_t)1 << 63); }
+        inline bool empty() const { return count == 0; }
+        void clear()
+        {
+            if (count || !b[kStage].empty()) {
+                uint64_t m = occupied;
+                while (m) { const int k = __builtin_ctzll(m); m &= m - 1; b[k].clear(); }
+                b[64].clear();
+                b[kStage].clear();
             }
-            heap[k] = last;
+            occupied = 0; top_bucket = false; started = false; count = 0;
         }
-        return top;
-    }
+        inline void file(const Item &it)
+        {
+            const uint64_t x = ukey(it.first) ^ last;
+            const int k = x ? 64 - __builtin_clzll(x) : 0;
+            b[k].push_back(it);
+            if (k < 64) occupied |= (uint64_t)1 << k; else top_bucket = true;
+        }
+        inline void push(const Item &it)
+        {
+            ++count;
+            if (!started) { b[kStage].push_back(it); return; }
+            if (ukey(it.first) < last) { b[0].push_back(it); occupied |= 1; return; }      // (cannot happen with feasible duals)
+            file(it);
+        }
+        Item pop()
+        {
+            if (!started) {
+                started = true;
+                uint64_t mn = ~(uint64_t)0;
+                for (const Item &it : b[kStage]) if (ukey(it.first) < mn) mn = ukey(it.first);
+                last = mn;
+                for (const Item &it : b[kStage]) file(it);
+                b[kStage].clear();
+            }
+            if (b[0].empty()) {
+                occupied &= ~(uint64_t)1;
+                const int k = occupied ? __builtin_ctzll(occupied) : 64;
+                std::vector<Item> &src = b[k];
+                uint64_t mn = ~(uint64_t)0;
+                for (const Item &it : src) if (ukey(it.first) < mn) mn = ukey(it.first);
+                last = mn;
+                if (k < 64) occupied &= ~((uint64_t)1 << k); else top_bucket = false;
+                spill.swap(src);
+                for (const Item &it : spill) file(it);
+                spill.clear();
+            }
+            const Item top = b[0].back();
+            b[0].pop_back();
+            if (b[0].empty()) occupied &= ~(uint64_t)1;
+            --count;
+            return top;
+        }
+        std::vector<Item> spill;
+        template <typename F> void for_each(F f) const
+        {
+            for (int k = 0; k < 66; ++k) for (const Item &it : b[k]) f(it);
+        }
+    } heap;
+    inline void heap_push(const Item &it) { heap.push(it); }
+    inline Item heap_pop() { return heap.pop(); }
 
     // false (concurrent mode only): the search met an older one and gave up; nothing was changed, insert the row again
     bool insert_row(int i) { return ticket > 0 ? insert_row_t<true>(i) : insert_row_t<false>(i); }
@@ -831,10 +870,10 @@ struct Lsap {
             else (cj.spc < team.theta ? me.near : me.far).push_back(j);
         };
         for (size_t k = 0; k < sc_cols.size(); ++k) seed(sc_cols[k], k + 1 < sc_cols.size());
-        for (const Item &it : heap) {
+        heap.for_each([&](const Item &it) {
             const Col &cj = c[it.second];
             if (cj.stamp == open && it.first == cj.spc && L.plabel[it.second].load(std::memory_order_relaxed) == Lsap::kNoLabel) seed(it.second, false);
-        }
+        });
         heap.clear();
         team.bound.store(bound, std::memory_order_relaxed);
         team.cursor.store(0);
