@@ -220,8 +220,11 @@ __global__ __launch_bounds__(NC > 0 ? 256 : 64) void hungarian_pair_kernel(
     st1 = HUNG_STAMP();
 #endif
     if constexpr (NC > 0) {
-        // ---- register-resident column state: column j = lane + 64*k lives in slot k of lane j % 64
-        constexpr int NS = NC > 0 ? NC : 1;
+        // ---- register-resident column state: column j = lane + 64*k lives in slot k of lane j % 64. The number of slots a search
+        // step walks is chosen per pair from its column count (block-uniform): a pair of 75 detections under cap = 144 pays for
+        // two slots, not three.
+        auto resident = [&](auto ns_tag) {
+        constexpr int NS = decltype(ns_tag)::value;
         long v_r[NS], spc_r[NS];
         int pred_r[NS], rc_r[NS];            // predecessor row in the search / matched row
         bool ok_r[NS], sc_r[NS];
@@ -335,6 +338,14 @@ __global__ __launch_bounds__(NC > 0 ? 256 : 64) void hungarian_pair_kernel(
         };
         if (cached) searches(std::true_type{});
         else searches(std::false_type{});
+        };
+        if constexpr (NC == 3) {
+            if (m <= 64) resident(std::integral_constant<int, 1>{});
+            else if (m <= 128) resident(std::integral_constant<int, 2>{});
+            else resident(std::integral_constant<int, 3>{});
+        } else {
+            resident(std::integral_constant<int, (NC > 0 ? NC : 1)>{});
+        }
     } else {
     for (int i = 0; i < n; ++i) {
             if (GAP == 2 && succ1[(long)t * cap + i] >= 0) continue;      // wave-uniform
@@ -409,20 +420,28 @@ __global__ __launch_bounds__(NC > 0 ? 256 : 64) void hungarian_pair_kernel(
 }
 
 // chains -> track ids, numbered by (first frame, index), in parallel:
-//   root[k]  = first detection of k's chain, by pointer doubling over the predecessor links (ceil(log2 F) rounds);
+//   root[k]  = first detection of k's chain, by pointer jumping over the predecessor links (ceil(log4 F) rounds);
 //   id[root] = rank of the root among all roots in slot order (one block-wide scan over the slots).
+// (four hops per launch: every launch costs ~5 us of queue time whatever it does, and a hop is one cached load)
+__device__ __forceinline__ int chain_parent(long s, const int *__restrict__ count, int cap, const int *__restrict__ pred1,
+                                            const int *__restrict__ pred2)
+{
+    const int t = s / cap, i = s - (long)t * cap;
+    if (i >= min(count[t], cap)) return -1;              // slots beyond count
+    const int p1 = (t >= 1) ? pred1[s] : -1;
+    const int p2 = (t >= 2) ? pred2[s] : -1;
+    return (p1 >= 0) ? (t - 1) * cap + p1 : (p2 >= 0) ? (t - 2) * cap + p2 : (int)s;
+}
+
 __global__ void chain_init_kernel(const int *__restrict__ count, int n_frames, int cap, const int *__restrict__ pred1,
                                   const int *__restrict__ pred2, int *__restrict__ root)
 {
     const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= (long)n_frames * cap) return;
-    const int t = s / cap, i = s - (long)t * cap;
-    int r = -1;                                           // slots beyond count
-    if (i < min(count[t], cap)) {
-        const int p1 = (t >= 1) ? pred1[s] : -1;
-        const int p2 = (t >= 2) ? pred2[s] : -1;
-        r = (p1 >= 0) ? (t - 1) * cap + p1 : (p2 >= 0) ? (t - 2) * cap + p2 : (int)s;
-    }
+    int r = chain_parent(s, count, cap, pred1, pred2);
+#pragma unroll
+    for (int hop = 0; hop < 3; ++hop)
+        if (r >= 0) r = chain_parent(r, count, cap, pred1, pred2);
     root[s] = r;
 }
 
@@ -430,8 +449,11 @@ __global__ void chain_jump_kernel(const int *__restrict__ in, int *__restrict__ 
 {
     const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
-    const int r = in[s];
-    out[s] = (r < 0) ? -1 : in[r];
+    int r = in[s];
+#pragma unroll
+    for (int hop = 0; hop < 3; ++hop)
+        if (r >= 0) r = in[r];
+    out[s] = r;
 }
 
 // ids of roots = exclusive prefix count of (root[s] == s) in slot order. Single block: every thread counts the roots
@@ -518,10 +540,10 @@ __global__ __launch_bounds__(1024) void chain_small_kernel(const int *__restrict
     }
 }
 
-__global__ void fill_int_kernel(int *p, long n, int v)
+__global__ void fill2_int_kernel(int *p, int *q, long n, int v)
 {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n) { p[s] = v; q[s] = v; }
 }
 
 }  // namespace
@@ -558,9 +580,7 @@ static int hungarian_pairs_impl(const int32_t *d_x, const int32_t *d_y, const in
     const long slots = (long)n_frames * cap;
     int *pred1 = d_pred, *pred2 = d_pred + slots;
     int *succ1 = d_work, *succ2 = succ1 + slots, *frame_off = succ2 + slots;
-    hipLaunchKernelGGL(fill_int_kernel, dim3((unsigned)((2 * slots + 255) / 256)), dim3(256), 0, st, succ1, 2 * slots, -1);
-    AXT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(fill_int_kernel, dim3((unsigned)((2 * slots + 255) / 256)), dim3(256), 0, st, pred1, 2 * slots, -1);
+    hipLaunchKernelGGL(fill2_int_kernel, dim3((unsigned)((2 * slots + 255) / 256)), dim3(256), 0, st, succ1, pred1, 2 * slots, -1);
     AXT_LAUNCH_CHECK();
     int rc = axt_frame_offsets(d_count, n_frames, cap, frame_off, st);
     if (rc) return rc;
@@ -670,7 +690,7 @@ extern "C" int axt_chain_tracks(const int32_t *d_count, int n_frames, int cap, c
     }
     hipLaunchKernelGGL(chain_init_kernel, dim3(nb), dim3(256), 0, st, d_count, n_frames, cap, pred1, pred2, ra);
     AXT_LAUNCH_CHECK();
-    for (int span = 1; span < n_frames; span *= 2) {
+    for (long span = 4; span < n_frames; span *= 4) {        // (chain_init_kernel has gone four hops already)
         hipLaunchKernelGGL(chain_jump_kernel, dim3(nb), dim3(256), 0, st, (const int *)ra, rb, slots);
         AXT_LAUNCH_CHECK();
         int *tmp = ra; ra = rb; rb = tmp;

@@ -414,7 +414,7 @@ def hungarian_assoc(x, y, count, H, W, dmax, cost_units, thr_units, max_dist=MAX
     pred = torch.empty((2 * slots,), dtype=torch.int32, device=dev)
     work = torch.empty((2 * slots + n_frames + 1,), dtype=torch.int32, device=dev)
     track = torch.empty((n_frames, cap), dtype=torch.int32, device=dev)
-    n_tracks = torch.zeros((1,), dtype=torch.int32, device=dev)
+    n_tracks = torch.empty((1,), dtype=torch.int32, device=dev)       # (axt_chain_tracks always writes it)
     a, b = (0, n_frames) if frame_range is None else frame_range
     lib = _lib.load()
     with torch.cuda.device(dev):
