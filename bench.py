@@ -331,20 +331,24 @@ def main():
     # A real timelapse is processed once: the pass over a FRESH timelapse object of the same frames (the kept-tile list is
     # computed again, the identity count that sizes IDed_dets_all is fetched instead of guessed from the previous pass),
     # timed after the timed region for the steady_state note of the line
-    fresh_ms = None
+    fresh_ms = fresh_next_ms = None
     if world == 1 and args.input == 'hbm':
         from axtrack_amd import detections as _det
-        _det._IDS_GUESS.clear()
-        tl_fresh = axtrack_amd.Timelapse(tl.frames, name='bench', mask=mask, device=dev)
-        torch.cuda.synchronize(dev)
-        t = time.perf_counter()
-        a = axtrack_amd.AxonDetections(model, tl_fresh, P, None)
-        a.detect_dataset(cache=None)
-        if args.associates:
-            a.assign_ids(None, None)
-        torch.cuda.synchronize(dev)
-        fresh_ms = round((time.perf_counter() - t) * 1e3, 3)
-        del a, tl_fresh
+        fresh_all = []
+        for _ in range(6 if not args.big else 2):
+            _det._IDS_GUESS.clear()
+            tl_fresh = axtrack_amd.Timelapse(tl.frames, name='bench', mask=mask, device=dev)
+            torch.cuda.synchronize(dev)
+            t = time.perf_counter()
+            a = axtrack_amd.AxonDetections(model, tl_fresh, P, None)
+            a.detect_dataset(cache=None)
+            if args.associates:
+                a.assign_ids(None, None)
+            torch.cuda.synchronize(dev)
+            fresh_all.append((time.perf_counter() - t) * 1e3)
+            del a, tl_fresh
+        fresh_ms = round(fresh_all[0], 3)
+        fresh_next_ms = round(sum(fresh_all[1:]) / len(fresh_all[1:]), 3)
 
     # the flow tracker's optimality certificate (axt_mcf_solve_duals): one more untimed step on every rank (the shared solve is
     # collective), checked on rank 0 in verify()
@@ -389,7 +393,8 @@ def main():
                                                 'is computed by the first pass and kept, and IDed_dets_all is sized from the identity count of the previous pass '
                                                 'over a timelapse of this shape instead of a device-to-host round trip; packed weights belong to the Detector',
                                         'fresh_timelapse_pass_ms': fresh_ms,
-                                        'fresh_timelapse_pass': 'one pass over a new Timelapse object of the same frames with the identity-count guess cleared (after the timed region)'},
+                                        'fresh_timelapse_next_passes_ms': fresh_next_ms,
+                                        'fresh_timelapse_pass': 'passes over NEW Timelapse objects of the same frames with the identity-count guess cleared (after the timed region): the first one, and the mean of the following ones (each again over a new object): the first also pays what a process pays once (allocator pools for the new buffers)'},
                        'cnn_arith': args.arith,
                        'conv_algorithm': ('Winograd F(2x2,3x3), f32, for the six stride-1 conv blocks (2,4,5,7,8,10); direct for the two stride-2 blocks'
                                           if winograd else 'direct') + ('; the two stride-2 blocks fused into one kernel' if getattr(model, 'fused_front', False) else '')},
