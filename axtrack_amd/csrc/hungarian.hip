@@ -456,27 +456,33 @@ __global__ void chain_jump_kernel(const int *__restrict__ in, int *__restrict__ 
     out[s] = r;
 }
 
-// ids of roots = exclusive prefix count of (root[s] == s) in slot order. Single block: every thread counts the roots
-// of one contiguous run of slots, the 1024 counts are scanned in LDS, then the thread numbers its roots.
+// ids of roots = exclusive prefix count of (root[s] == s) in slot order. Single block, 1024 slots per round in slot order
+// (coalesced): a wave ballots its roots, the sixteen wave counts go through LDS, the running total carries over. The next round's
+// slots are loaded before this round's barriers.
 __global__ __launch_bounds__(1024) void chain_rank_kernel(const int *__restrict__ root, long n, int *__restrict__ rank,
                                                           int *__restrict__ n_tracks)
 {
-    __shared__ int cnt[1024];
-    const long per = (n + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
-    int c = 0;
-    for (long s = lo; s < hi; ++s) c += root[s] == (int)s;
-    cnt[threadIdx.x] = c;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const int t = threadIdx.x >= o ? cnt[threadIdx.x - o] : 0;
-        __syncthreads();
-        cnt[threadIdx.x] += t;
-        __syncthreads();
+    __shared__ int wsum[2][16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int base = 0, par = 0;
+    long s = threadIdx.x;
+    int r = s < n ? root[s] : -2;
+    for (long s0 = 0; s0 < n; s0 += 1024, par ^= 1) {
+        const long sn = s + 1024;
+        const int rn = sn < n ? root[sn] : -2;
+        const bool is_root = r == (int)s;                    // (r = -2 beyond n, -1 in empty slots)
+        const unsigned long long m = __ballot(is_root);
+        if (lane == 0) wsum[par][w] = __popcll(m);
+        __syncthreads();                                     // (two sets of counts: one barrier per round)
+        int off = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const int v = wsum[par][k]; off += k < w ? v : 0; tot += v; }
+        if (is_root) rank[s] = base + off + __popcll(m & ((1ull << lane) - 1));
+        base += tot;
+        s = sn;
+        r = rn;
     }
-    int id = cnt[threadIdx.x] - c;
-    for (long s = lo; s < hi; ++s)
-        if (root[s] == (int)s) rank[s] = id++;
-    if (threadIdx.x == 1023) *n_tracks = cnt[1023];
+    if (threadIdx.x == 0) *n_tracks = base;
 }
 
 __global__ void chain_assign_kernel(const int *__restrict__ root, const int *__restrict__ rank, int *__restrict__ track, long n)
