@@ -457,30 +457,38 @@ __global__ void chain_jump_kernel(const int *__restrict__ in, int *__restrict__ 
 }
 
 // ids of roots = exclusive prefix count of (root[s] == s) in slot order. Single block, 1024 slots per round in slot order
-// (coalesced): a wave ballots its roots, the sixteen wave counts go through LDS, the running total carries over. The next round's
-// slots are loaded before this round's barriers.
+// (coalesced): a wave ballots its roots, the sixteen wave counts go through LDS, the running total carries over. The loads of
+// sixteen rounds are issued together (one memory latency per 16 k slots instead of one per round).
 __global__ __launch_bounds__(1024) void chain_rank_kernel(const int *__restrict__ root, long n, int *__restrict__ rank,
                                                           int *__restrict__ n_tracks)
 {
+    constexpr int R = 16;                                    // rounds per batch (even: the two sets of counts alternate)
     __shared__ int wsum[2][16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int base = 0, par = 0;
-    long s = threadIdx.x;
-    int r = s < n ? root[s] : -2;
-    for (long s0 = 0; s0 < n; s0 += 1024, par ^= 1) {
-        const long sn = s + 1024;
-        const int rn = sn < n ? root[sn] : -2;
-        const bool is_root = r == (int)s;                    // (r = -2 beyond n, -1 in empty slots)
-        const unsigned long long m = __ballot(is_root);
-        if (lane == 0) wsum[par][w] = __popcll(m);
-        __syncthreads();                                     // (two sets of counts: one barrier per round)
-        int off = 0, tot = 0;
+    int base = 0;
+    for (long b0 = 0; b0 < n; b0 += 1024 * R) {
+        int r[R];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { const int v = wsum[par][k]; off += k < w ? v : 0; tot += v; }
-        if (is_root) rank[s] = base + off + __popcll(m & ((1ull << lane) - 1));
-        base += tot;
-        s = sn;
-        r = rn;
+        for (int q = 0; q < R; ++q) {
+            const long s = b0 + q * 1024 + threadIdx.x;
+            r[q] = s < n ? root[s] : -2;                     // (-2 beyond n, -1 in empty slots: never equal to a slot)
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const long s = b0 + q * 1024 + threadIdx.x;
+            if (b0 + q * 1024 < n) {                         // (block-uniform: the rounds beyond n are skipped by everybody)
+                const bool is_root = r[q] == (int)s;
+                const unsigned long long m = __ballot(is_root);
+                if (lane == 0) wsum[q & 1][w] = __popcll(m);
+                __syncthreads();                             // (two sets of counts: one barrier per round)
+                int off = 0, tot = 0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { const int v = wsum[q & 1][k]; off += k < w ? v : 0; tot += v; }
+                if (is_root) rank[s] = base + off + __popcll(m & ((1ull << lane) - 1));
+                base += tot;
+            }
+        }
+        __syncthreads();                                     // (a batch may end on either set)
     }
     if (threadIdx.x == 0) *n_tracks = base;
 }
