@@ -231,10 +231,14 @@ def decode_stitch_nms(yolo, tile_yx, conf_thr=CONF_FLOOR, min_dist=23, cap=None)
     assert len(tile_yx) == n_tiles and yolo.is_contiguous()
     cap = cap or n_tiles * CELLS
     dev = yolo.device
-    conf = torch.zeros((n_frames, cap), dtype=torch.float32, device=dev)
-    x = torch.zeros((n_frames, cap), dtype=torch.int32, device=dev)
-    y = torch.zeros((n_frames, cap), dtype=torch.int32, device=dev)
-    count = torch.zeros((n_frames,), dtype=torch.int32, device=dev)
+    # one zeroed block for the four outputs (one fill launch instead of four; slots beyond a frame's count stay zero)
+    slots = n_frames * cap
+    sec = (slots + 63) // 64 * 64                        # every output starts 256-byte aligned, like a tensor of its own
+    block = torch.zeros((3 * sec + n_frames,), dtype=torch.int32, device=dev)
+    conf = block[:slots].view(torch.float32).view(n_frames, cap)
+    x = block[sec:sec + slots].view(n_frames, cap)
+    y = block[2 * sec:2 * sec + slots].view(n_frames, cap)
+    count = block[3 * sec:]
     lib = _lib.load()
     with torch.cuda.device(dev):
         _lib.check(lib.axt_decode_stitch_nms(yolo.data_ptr(), n_frames, n_tiles, tile_yx.ctypes.data,
