@@ -563,6 +563,23 @@ def test_a_large_search_finished_by_a_team_of_threads_changes_nothing(threads, m
         assert res[3] == ref[3] and np.array_equal(res[1], ref[1])
         monkeypatch.delenv('AXT_MCF_PAR_MIN_N')
 
+def test_flow_solver_on_forty_random_scenes_equals_its_other_regime_and_carries_a_certificate(monkeypatch):
+    """Forty scenes of moving cones of random length and density, the time-block tree forced onto them with a random leaf size:
+    the assignment-form solver (searches on a monotone radix heap: a search never pushes a key below the last one it popped, which
+    is what the heap's buckets rely on) ends with the trajectories and the cost of the successive-shortest-path regime, and its
+    duals certify the optimum."""
+    from helpers import moving_network, check_flow_certificate
+    for seed in range(40):
+        rng = np.random.default_rng(seed)
+        net = moving_network(int(rng.integers(20, 90)), 512, int(rng.integers(10, 80)), seed=seed)[:6]
+        monkeypatch.setenv('AXT_MCF_MIN_LEAF', str(int(rng.integers(16, 400))))
+        got = hp.mcf_solve(*net, 5, 100000, duals=True)
+        monkeypatch.setenv('AXT_MCF_FORCE_SSP', '1')
+        ref = hp.mcf_solve(*net, 5, 100000)
+        monkeypatch.delenv('AXT_MCF_FORCE_SSP')
+        assert got[2] == ref[2] and got[3] == ref[3] and np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), seed
+        check_flow_certificate(*net, got[0], got[1], got[3], got[4], 5, 100000)
+
 
 def test_launch_attributes_are_remembered_per_device_not_per_process(tmp_path):
     """hipFuncSetAttribute acts on the CURRENT device: the launchers remember per device index what they have set
